@@ -1,0 +1,193 @@
+/*
+ * mi355rt.h — C ABI of libmi355rt.so, the MI355X (gfx950) render path behind
+ * raytracer-rs's `raytracer_lib` API.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to
+ * /root/reference/raytracer_lib/src).  Conventions:
+ *   - plain pointers and sizes only; the caller owns every input pointer, the library copies
+ *     during `create`; output buffers are caller-allocated;
+ *   - functions return 0 on success or a negative MI355RT_E_* code, and
+ *     mi355rt_last_error() then returns the message the reference would carry in its
+ *     `Result<_, String>` (lib.rs:15-27);
+ *   - a handle may be created on one thread and used on another (main.rs:183,194-196): every
+ *     entry binds the handle's HIP device; calls on ONE handle must not overlap;
+ *   - there is NO CPU fallback: without a usable HIP device `create` fails with
+ *     MI355RT_E_NO_DEVICE.
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355RT_OK            0
+#define MI355RT_E_INVALID    -1   /* bad argument */
+#define MI355RT_E_NO_DEVICE  -2   /* no HIP device / HIP runtime error */
+#define MI355RT_E_LOAD       -3   /* scene load error (SceneLoadError, loaders/mod.rs:20-25) */
+#define MI355RT_E_HIP        -4   /* HIP runtime error after creation */
+
+/* DEFAULT_TRIANGLES_PER_LEAF, oct_tree_intersector.rs:12 / lib.rs:7 */
+#define MI355RT_DEFAULT_TRIANGLES_PER_LEAF 70u
+
+/* Config.flags */
+#define MI355RT_FLAG_FIX_ROW_INDEX  1u  /* v = idx / width instead of the reference's idx / height (mod.rs:93-96) */
+#define MI355RT_FLAG_COUNT_STEPS    2u  /* instrumented traversal: count BVH nodes visited / triangles tested */
+#define MI355RT_FLAG_TIME_KERNELS   4u  /* bracket every trace-kernel launch with HIP events */
+
+typedef struct mi355rt_handle mi355rt_handle;
+
+/* Material.diffuse, scene/mod.rs:63-69 + color.rs:98-108.  kind 0 = Diffuse::Color(rgb),
+ * kind 1 = Diffuse::TextureId(tex_id).  emissive/specular/ior are never read by shading. */
+typedef struct mi355rt_material {
+    uint32_t kind;
+    float rgb[3];
+    uint32_t tex_id;
+} mi355rt_material;
+
+/* Light, scene/mod.rs:12-16 */
+typedef struct mi355rt_light {
+    float pos[3];
+    float color[3];
+} mi355rt_light;
+
+/* Texture, scene/texture.rs:6-10: width*height RGB f32 texels (byte/256.0), row-major */
+typedef struct mi355rt_texture {
+    uint32_t width, height;
+    const float* rgb;
+} mi355rt_texture;
+
+/* Scene, scene/mod.rs:18-23, flattened: one triangle soup in geometry order (= visual-scene
+ * node order), tri_geom[i] = index of the geometry (and of its material) triangle i belongs to;
+ * camera = the arguments of Camera::from_orientation_matrix for scene.cameras[0]
+ * (camera.rs:22-27, lib.rs:39). */
+typedef struct mi355rt_scene_desc {
+    const float* tri_verts;          /* ntri * 9 floats, world space */
+    const uint32_t* tri_geom;        /* ntri */
+    uint32_t ntri;
+    const mi355rt_material* materials;
+    uint32_t nmaterials;
+    const mi355rt_light* lights;
+    uint32_t nlights;
+    const mi355rt_texture* textures;
+    uint32_t ntextures;
+    float camera_orientation[16];    /* vecmath Matrix (row-vector convention) */
+    float camera_fov_deg;
+} mi355rt_scene_desc;
+
+typedef struct mi355rt_config {
+    uint32_t width, height;          /* create_raytracer(.., width, height), lib.rs:15 */
+    uint32_t triangles_per_leaf;     /* accepted for API parity; the BVH uses its own leaf size */
+    uint32_t recursions;             /* RECURSIONS = 2, mod.rs:81 (0 selects the default) */
+    uint32_t spread;                 /* SUB_SPREAD = 1, mod.rs:82 (0 selects the default) */
+    uint32_t flags;                  /* MI355RT_FLAG_* */
+    uint64_t seed;                   /* counter-RNG seed (the reference draws OS entropy) */
+    int32_t device;                  /* HIP device ordinal */
+    /* Row-stripe ownership for multi-GPU rendering: this handle renders the stripes of
+     * `stripe_rows` rows whose index is congruent to stripe_rank modulo stripe_world.
+     * stripe_world <= 1 renders every row. */
+    uint32_t stripe_rows, stripe_rank, stripe_world;
+    uint32_t samples_per_pass;       /* samples per pixel traced per wavefront pass (0 = auto) */
+} mi355rt_config;
+
+/* Ray counters of one mi355rt_render / mi355rt_trace_frame_additive call. */
+typedef struct mi355rt_ray_counts {
+    uint64_t primary;        /* primary samples (the reference's own rays/s metric, stats.rs:27) */
+    uint64_t bounce;         /* reflection rays, mod.rs:156-158 */
+    uint64_t shadow;         /* shadow rays, mod.rs:226 */
+    uint64_t primary_hits;
+    uint64_t nodes_visited;  /* only with MI355RT_FLAG_COUNT_STEPS */
+    uint64_t tris_tested;    /* only with MI355RT_FLAG_COUNT_STEPS */
+    uint64_t trace_launches; /* trace-kernel launches */
+    double trace_ms;         /* summed HIP-event time of the trace kernels (MI355RT_FLAG_TIME_KERNELS) */
+    double total_ms;         /* HIP-event time of the whole call on the handle's stream */
+} mi355rt_ray_counts;
+
+void mi355rt_default_config(mi355rt_config* cfg);
+
+/* build_raytracer, lib.rs:29-44 (octree build replaced by a BVH build + upload). */
+int mi355rt_create(const mi355rt_scene_desc* scene, const mi355rt_config* cfg, mi355rt_handle** out);
+/* create_raytracer(collada_doc, triangles_per_leaf, width, height), lib.rs:15-20.
+ * data_dir (may be NULL) is where texture files are looked up (colladaloader.rs:146-150). */
+int mi355rt_create_from_collada_str(const char* doc, size_t len, const char* data_dir,
+                                    const mi355rt_config* cfg, mi355rt_handle** out);
+/* create_raytracer_from_file(collada_filename, ...), lib.rs:22-27 */
+int mi355rt_create_from_collada_file(const char* path, const mi355rt_config* cfg, mi355rt_handle** out);
+/* flat scene container written by tools/dae2scene (no reference counterpart) */
+int mi355rt_create_from_scene_file(const char* path, const mi355rt_config* cfg, mi355rt_handle** out);
+void mi355rt_destroy(mi355rt_handle* h);
+
+/* Error text of the last failed call; h == NULL returns the last creation error of this thread. */
+const char* mi355rt_last_error(const mi355rt_handle* h);
+
+/* RayTracer::trace_frame_additive, mod.rs:80-117: 50 rows x width pixels x 1 sample, row cursor
+ * wraps modulo height; returns 50*width (0 on error).  With stripes, only owned rows are traced. */
+uint32_t mi355rt_trace_frame_additive(mi355rt_handle* h);
+/* Whole frame (owned stripes) x spp samples per pixel — the benchmark entry; no reference
+ * counterpart (the reference has no spp concept).  counts may be NULL. */
+int mi355rt_render(mi355rt_handle* h, uint32_t spp, mi355rt_ray_counts* counts);
+/* counters of the last trace_frame_additive / render call */
+int mi355rt_last_counts(const mi355rt_handle* h, mi355rt_ray_counts* counts);
+
+/* RayTracer::get_tonemapped_pixels, mod.rs:120-128: width*height u32 0xAARRGGBB (A = 255). */
+int mi355rt_get_tonemapped_pixels(mi355rt_handle* h, uint32_t* out, size_t n);
+/* Same, written to DEVICE memory on the handle's device (e.g. a buffer owned by the caller's
+ * collective library).  Rows owned by this handle only, packed in ascending row order:
+ * mi355rt_owned_rows(h) * width values.  Synchronous with respect to the host. */
+int mi355rt_tonemap_owned_rows_device(mi355rt_handle* h, uint32_t* device_out, size_t n);
+uint32_t mi355rt_owned_rows(const mi355rt_handle* h);
+/* ascending list of the rows this handle owns */
+int mi355rt_owned_row_list(const mi355rt_handle* h, uint32_t* rows, size_t n);
+
+/* Film, film.rs:27-68.  pixel_datas: sum_rgb / sumsq_rgb hold width*height*3 floats, n holds
+ * width*height counts; any pointer may be NULL. */
+int mi355rt_film_get(mi355rt_handle* h, float* sum_rgb, float* sumsq_rgb, uint32_t* n);
+int mi355rt_film_clear(mi355rt_handle* h);                                   /* Film::clear, film.rs:37-41 */
+int mi355rt_film_get_pixels(mi355rt_handle* h, float* rgb);                  /* Film::get_pixels, film.rs:43-47 */
+int mi355rt_film_get_estimated_variances(mi355rt_handle* h, float* rgb);     /* film.rs:51-67 */
+
+/* Camera, camera.rs:63-78 (the `pub camera` field of RayTracer, mod.rs:38). */
+int mi355rt_camera_move_rel(mi355rt_handle* h, float x, float y, float z);
+int mi355rt_camera_add_x_angle(mi355rt_handle* h, float radians);
+int mi355rt_camera_add_y_angle(mi355rt_handle* h, float radians);
+/* rotation_matrix / orientation_matrix after update_matrices (camera.rs:92-98), max_x, max_y */
+int mi355rt_camera_get(const mi355rt_handle* h, float rot16[16], float orient16[16], float max_xy[2]);
+/* Camera::get_ray, camera.rs:80-90, with explicit jitter (xi1, xi2 in [0,1)): out = pos3, dir3 */
+int mi355rt_camera_get_ray(const mi355rt_handle* h, uint32_t u, uint32_t v, float xi1, float xi2, float ray6[6]);
+
+int mi355rt_set_seed(mi355rt_handle* h, uint64_t seed);
+int mi355rt_set_flags(mi355rt_handle* h, uint32_t flags);
+
+/* Intersector::intersect_ray, accel_intersect.rs:10-13, batched on the device: rays6 = n x
+ * (pos3, dir3); out tuv = n x 3 (untouched on a miss), prim = n global triangle indices
+ * (0xFFFFFFFF on a miss; geometry_index = tri_geom[prim], vertex_index = 3 * index within
+ * the geometry, mod.rs:17-21).  Returns the TRUE closest hit (no_acceleration_intersector.rs
+ * semantics: lowest t, ties to the lowest triangle index). */
+int mi355rt_intersect_rays(mi355rt_handle* h, const float* rays6, size_t n, float* tuv, uint32_t* prim);
+/* shadow-ray predicate of shade(), mod.rs:222-230: blocked[i] = 1 iff the closest hit of ray i
+ * has 0.01 < t < 1.0 */
+int mi355rt_occluded_rays(mi355rt_handle* h, const float* rays6, size_t n, uint8_t* blocked);
+
+/* SampleGenerator table, sample_generator.rs:15-24: 65 536 x 3 floats */
+int mi355rt_get_sample_table(const mi355rt_handle* h, float* out);
+/* Per-node direct-light terms of one primary sample, computed on the device by the same
+ * kernels as a frame (stage-level parity): node_L = nodes x 3 floats (breadth-first radiance
+ * tree, black where not reached), color3 = the sample's radiance.  Does not touch the film. */
+int mi355rt_debug_sample(mi355rt_handle* h, uint32_t pixel, uint32_t sampleno, float color3[3], float* node_L, size_t nodes);
+uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
+
+/* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,
+ * [4] node bytes, [5] triangle bytes, [6] nodes staged in LDS, [7] reserved */
+int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8]);
+uint32_t mi355rt_width(const mi355rt_handle* h);
+uint32_t mi355rt_height(const mi355rt_handle* h);
+uint32_t mi355rt_triangle_count(const mi355rt_handle* h);
+uint32_t mi355rt_current_row(const mi355rt_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RT_H */

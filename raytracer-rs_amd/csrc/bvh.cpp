@@ -1,0 +1,184 @@
+// bvh.cpp — binned-SAH BVH2 builder, see bvh.hpp.
+#include "bvh.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+
+namespace mi355rt {
+namespace {
+
+struct Box {
+    float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+    void grow(const float* p) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); } }
+    float half_area() const
+    {
+        float d[3] = { mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2] };
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0f;
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+    }
+};
+
+struct TmpNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; uint32_t depth = 0; };
+
+struct Builder {
+    const float* verts;
+    std::vector<Box> tri_box;
+    std::vector<float> centroid;     // ntri*3
+    std::vector<uint32_t> order;
+    std::vector<TmpNode> tmp;
+
+    static uint32_t levels_needed(uint32_t n)
+    {
+        uint32_t l = 0;
+        while ((kBvhMaxLeaf << l) < n) ++l;
+        return l;
+    }
+
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        TmpNode node;
+        node.first = first; node.count = count; node.depth = depth;
+        Box cbox;
+        for (uint32_t i = first; i < first + count; ++i) { node.box.grow(tri_box[order[i]]); cbox.grow(&centroid[3 * order[i]]); }
+        int32_t idx = (int32_t)tmp.size();
+        tmp.push_back(node);
+        if (count <= 1) return idx;
+
+        constexpr int NB = 16;
+        float best_cost = 3.4e38f; int best_axis = -1, best_bin = -1;
+        bool force_balanced = depth + levels_needed(count) + 1 >= kBvhMaxDepth;
+        if (!force_balanced) {
+            for (int a = 0; a < 3; ++a) {
+                float lo = cbox.mn[a], hi = cbox.mx[a];
+                if (!(hi > lo)) continue;
+                float scale = NB / (hi - lo);
+                Box bb[NB]; uint32_t bc[NB] = { 0 };
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = std::min(NB - 1, (int)((centroid[3 * order[i] + a] - lo) * scale));
+                    bb[b].grow(tri_box[order[i]]); bc[b]++;
+                }
+                float right_area[NB]; uint32_t right_cnt[NB];
+                Box acc; uint32_t c = 0;
+                for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); c += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = c; }
+                Box lacc; uint32_t lc = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    lacc.grow(bb[b]); lc += bc[b];
+                    if (lc == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = lacc.half_area() * lc + right_area[b + 1] * right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+        }
+        if (count <= kBvhMaxLeaf) {
+            // leaf unless the split is clearly cheaper (traversal step ~ 1.5 triangle tests)
+            float leaf_cost = node.box.half_area() * (float)count;
+            float split_cost = best_axis >= 0 ? best_cost + 1.5f * node.box.half_area() : 3.4e38f;
+            if (!(split_cost < leaf_cost)) return idx;
+        }
+        uint32_t mid;
+        if (best_axis >= 0) {
+            float lo = cbox.mn[best_axis], hi = cbox.mx[best_axis];
+            float scale = NB / (hi - lo);
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                int b = std::min(NB - 1, (int)((centroid[3 * t + best_axis] - lo) * scale));
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(it - order.begin());
+        } else {
+            // no usable SAH split (coincident centroids or depth budget): median along the widest axis
+            int a = 0;
+            float d[3] = { cbox.mx[0] - cbox.mn[0], cbox.mx[1] - cbox.mn[1], cbox.mx[2] - cbox.mn[2] };
+            if (d[1] > d[a]) a = 1;
+            if (d[2] > d[a]) a = 2;
+            mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](uint32_t x, uint32_t y) { return centroid[3 * x + a] < centroid[3 * y + a]; });
+        }
+        if (mid == first || mid == first + count) mid = first + count / 2;
+        int32_t l = build(first, mid - first, depth + 1);
+        int32_t r = build(mid, first + count - mid, depth + 1);
+        tmp[idx].left = l; tmp[idx].right = r;
+        return idx;
+    }
+};
+
+int32_t leaf_code(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+}  // namespace
+
+void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out)
+{
+    out = Bvh();
+    if (ntri == 0) {
+        // one empty leaf is not representable (count >= 1): a degenerate triangle that can never
+        // be hit (|det| < EPSILON) keeps the kernels free of an "empty scene" special case
+        BvhTri t; std::memset(&t, 0, sizeof t); t.prim = 0xFFFFFFFFu;
+        out.tris.push_back(t);
+        out.root = leaf_code(0, 1);
+        out.leaves = 1; out.max_leaf = 1;
+        return;
+    }
+    Builder b;
+    b.verts = tri_verts;
+    b.tri_box.resize(ntri); b.centroid.resize((size_t)ntri * 3); b.order.resize(ntri);
+    Box scene;
+    for (uint32_t t = 0; t < ntri; ++t) {
+        for (int v = 0; v < 3; ++v) b.tri_box[t].grow(&tri_verts[9 * t + 3 * v]);
+        for (int a = 0; a < 3; ++a) b.centroid[3 * t + a] = 0.5f * (b.tri_box[t].mn[a] + b.tri_box[t].mx[a]);
+        b.order[t] = t;
+        scene.grow(b.tri_box[t]);
+    }
+    std::memcpy(out.scene_min, scene.mn, 12); std::memcpy(out.scene_max, scene.mx, 12);
+    b.tmp.reserve(2 * (size_t)ntri);
+    int32_t root = b.build(0, ntri, 0);
+
+    // Conservative padding: the exact (unfused f32) triangle test decides hits; a box test must
+    // never reject a ray the triangle test would accept, so every box is grown by `pad`.
+    float diag = std::sqrt((scene.mx[0] - scene.mn[0]) * (scene.mx[0] - scene.mn[0]) + (scene.mx[1] - scene.mn[1]) * (scene.mx[1] - scene.mn[1])
+                           + (scene.mx[2] - scene.mn[2]) * (scene.mx[2] - scene.mn[2]));
+    float pad = std::max(diag * 2e-5f, 1e-6f);
+
+    // breadth-first numbering of inner nodes; leaves get triangle ranges in visit order
+    std::vector<int32_t> inner_index(b.tmp.size(), -1);
+    std::vector<int32_t> bfs;
+    if (b.tmp[root].left >= 0) {
+        std::queue<int32_t> q; q.push(root);
+        while (!q.empty()) {
+            int32_t n = q.front(); q.pop();
+            inner_index[n] = (int32_t)bfs.size(); bfs.push_back(n);
+            for (int32_t c : { b.tmp[n].left, b.tmp[n].right }) if (b.tmp[c].left >= 0) q.push(c);
+        }
+    }
+    auto emit_leaf = [&](const TmpNode& n) -> int32_t {
+        uint32_t first = (uint32_t)out.tris.size();
+        for (uint32_t i = n.first; i < n.first + n.count; ++i) {
+            uint32_t t = b.order[i];
+            const float* v = &tri_verts[9 * t];
+            BvhTri r; std::memset(&r, 0, sizeof r);
+            for (int a = 0; a < 3; ++a) { r.v0[a] = v[a]; r.e1[a] = v[3 + a] - v[a]; r.e2[a] = v[6 + a] - v[a]; }
+            r.prim = t; r.geom = tri_geom[t];
+            out.tris.push_back(r);
+        }
+        out.leaves++; out.max_leaf = std::max(out.max_leaf, n.count); out.max_depth = std::max(out.max_depth, n.depth);
+        return leaf_code(first, n.count);
+    };
+    if (bfs.empty()) { out.root = emit_leaf(b.tmp[root]); return; }
+    out.nodes.resize(bfs.size());
+    for (size_t i = 0; i < bfs.size(); ++i) {
+        const TmpNode& n = b.tmp[bfs[i]];
+        const TmpNode& c0 = b.tmp[n.left];
+        const TmpNode& c1 = b.tmp[n.right];
+        BvhNode& o = out.nodes[i];
+        o.q0[0] = c0.box.mn[0] - pad; o.q0[1] = c0.box.mx[0] + pad; o.q0[2] = c0.box.mn[1] - pad; o.q0[3] = c0.box.mx[1] + pad;
+        o.q1[0] = c1.box.mn[0] - pad; o.q1[1] = c1.box.mx[0] + pad; o.q1[2] = c1.box.mn[1] - pad; o.q1[3] = c1.box.mx[1] + pad;
+        o.q2[0] = c0.box.mn[2] - pad; o.q2[1] = c0.box.mx[2] + pad; o.q2[2] = c1.box.mn[2] - pad; o.q2[3] = c1.box.mx[2] + pad;
+        o.child[0] = c0.left >= 0 ? inner_index[n.left] : emit_leaf(c0);
+        o.child[1] = c1.left >= 0 ? inner_index[n.right] : emit_leaf(c1);
+        o.child[2] = o.child[3] = 0;
+    }
+    out.root = 0;
+}
+
+}  // namespace mi355rt

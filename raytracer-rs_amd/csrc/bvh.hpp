@@ -1,0 +1,40 @@
+// bvh.hpp — host-side BVH2 build (binned SAH) and GPU-friendly flattening.
+// Replaces the reference's octree build (oct_tree_intersector.rs:66-146) — setup, runs once.
+// The traversal over this structure returns the TRUE closest hit, i.e. the semantics of the
+// reference's NoAccelerationIntersector (no_acceleration_intersector.rs:13-41): the octree's
+// "hit point must lie in the leaf cube" rule (OCT:160-169) is a property of that structure,
+// not of the scene, and is not reproduced here ("Octree vs BVH").
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace mi355rt {
+
+// 64-byte node holding BOTH child boxes (one fetch decides both children).
+//   q0 = (c0.min.x, c0.max.x, c0.min.y, c0.max.y)
+//   q1 = (c1.min.x, c1.max.x, c1.min.y, c1.max.y)
+//   q2 = (c0.min.z, c0.max.z, c1.min.z, c1.max.z)
+//   q3 = (child0, child1, 0, 0) as int32: >= 0 inner node index, < 0 leaf: ~v = first<<3 | count-1
+struct alignas(16) BvhNode { float q0[4], q1[4], q2[4]; int32_t child[4]; };
+static_assert(sizeof(BvhNode) == 64, "node must be 64 bytes");
+
+// 48-byte triangle in leaf order: v0 + the two edges the reference computes per test
+// (intersect.rs:65-66: v0v1 = v1 - v0, v0v2 = v2 - v0 — same f32 subtractions, done once).
+struct alignas(16) BvhTri { float v0[3]; uint32_t prim; float e1[3]; uint32_t geom; float e2[3]; uint32_t pad; };
+static_assert(sizeof(BvhTri) == 48, "triangle must be 48 bytes");
+
+struct Bvh {
+    std::vector<BvhNode> nodes;      // breadth-first: the top of the tree has the lowest indices
+    std::vector<BvhTri> tris;        // leaf order
+    int32_t root = 0;                // node index, or a leaf code when the scene is a single leaf
+    uint32_t leaves = 0, max_depth = 0, max_leaf = 0;
+    float scene_min[3] = { 0, 0, 0 }, scene_max[3] = { 0, 0, 0 };
+};
+
+constexpr uint32_t kBvhMaxDepth = 31;     // traversal stack holds this many deferred children
+constexpr uint32_t kBvhMaxLeaf = 4;
+
+// tri_verts: ntri*9 world-space floats, tri_geom: ntri geometry indices.
+void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out);
+
+}  // namespace mi355rt

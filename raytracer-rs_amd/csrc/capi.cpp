@@ -1,0 +1,270 @@
+// capi.cpp — the extern "C" surface declared in include/mi355rt.h.
+#include <cstring>
+#include <memory>
+#include <string>
+#include "../../include/mi355rt.h"
+#include "renderer.hpp"
+
+using namespace mi355rt;
+
+struct mi355rt_handle {
+    std::unique_ptr<Renderer> r;
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+int finish_create(const SceneData& scene, const mi355rt_config* cfg, mi355rt_handle** out)
+{
+    int code = MI355RT_E_INVALID;
+    std::string err;
+    std::unique_ptr<Renderer> r = Renderer::create(scene, *cfg, err, code);
+    if (!r) { g_create_error = err; return code; }
+    *out = new mi355rt_handle{ std::move(r) };
+    return MI355RT_OK;
+}
+int bad(const char* msg) { g_create_error = msg; return MI355RT_E_INVALID; }
+}  // namespace
+
+extern "C" {
+
+void mi355rt_default_config(mi355rt_config* cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->width = 1024; cfg->height = 768;                         // DEFAULT_WIDTH / DEFAULT_HEIGHT, main.rs:13-14
+    cfg->triangles_per_leaf = MI355RT_DEFAULT_TRIANGLES_PER_LEAF;
+    cfg->recursions = 2; cfg->spread = 1;                         // mod.rs:81-82
+    cfg->seed = 1; cfg->device = 0;
+    cfg->stripe_rows = 8; cfg->stripe_rank = 0; cfg->stripe_world = 1;
+}
+
+int mi355rt_create(const mi355rt_scene_desc* s, const mi355rt_config* cfg, mi355rt_handle** out)
+{
+    if (!s || !cfg || !out) return bad("null argument");
+    *out = nullptr;
+    if ((s->ntri && (!s->tri_verts || !s->tri_geom)) || (s->nmaterials && !s->materials) || (s->nlights && !s->lights) || (s->ntextures && !s->textures))
+        return bad("null array with a non-zero count");
+    SceneData sd;
+    sd.tri_verts.assign(s->tri_verts, s->tri_verts + (size_t)s->ntri * 9);
+    sd.tri_geom.assign(s->tri_geom, s->tri_geom + s->ntri);
+    for (uint32_t i = 0; i < s->nmaterials; ++i) {
+        MaterialData m;
+        m.kind = s->materials[i].kind; std::memcpy(m.rgb, s->materials[i].rgb, 12); m.tex_id = s->materials[i].tex_id;
+        if (m.kind > 1) return bad("material kind must be 0 (colour) or 1 (texture)");
+        sd.materials.push_back(m);
+    }
+    for (uint32_t i = 0; i < s->nlights; ++i) {
+        LightData l;
+        std::memcpy(l.pos, s->lights[i].pos, 12); std::memcpy(l.color, s->lights[i].color, 12);
+        sd.lights.push_back(l);
+    }
+    for (uint32_t i = 0; i < s->ntextures; ++i) {
+        TextureData t;
+        t.width = s->textures[i].width; t.height = s->textures[i].height;
+        if (!s->textures[i].rgb || !t.width || !t.height) return bad("empty texture");
+        t.rgb.assign(s->textures[i].rgb, s->textures[i].rgb + (size_t)t.width * t.height * 3);
+        sd.textures.push_back(std::move(t));
+    }
+    CameraData c;
+    std::memcpy(c.orientation, s->camera_orientation, 64); c.fov_deg = s->camera_fov_deg;
+    sd.cameras.push_back(c);
+    return finish_create(sd, cfg, out);
+}
+
+int mi355rt_create_from_collada_str(const char* doc, size_t len, const char* data_dir, const mi355rt_config* cfg, mi355rt_handle** out)
+{
+    if (!doc || !cfg || !out) return bad("null argument");
+    *out = nullptr;
+    SceneData sd; std::string err;
+    if (!load_collada_str(std::string(doc, len), data_dir, sd, err)) { g_create_error = err; return MI355RT_E_LOAD; }
+    return finish_create(sd, cfg, out);
+}
+
+int mi355rt_create_from_collada_file(const char* path, const mi355rt_config* cfg, mi355rt_handle** out)
+{
+    if (!path || !cfg || !out) return bad("null argument");
+    *out = nullptr;
+    SceneData sd; std::string err;
+    if (!load_collada_file(path, sd, err)) { g_create_error = err; return MI355RT_E_LOAD; }
+    return finish_create(sd, cfg, out);
+}
+
+int mi355rt_create_from_scene_file(const char* path, const mi355rt_config* cfg, mi355rt_handle** out)
+{
+    if (!path || !cfg || !out) return bad("null argument");
+    *out = nullptr;
+    SceneData sd; std::string err;
+    if (!read_scene_file(path, sd, err)) { g_create_error = err; return MI355RT_E_LOAD; }
+    return finish_create(sd, cfg, out);
+}
+
+void mi355rt_destroy(mi355rt_handle* h) { delete h; }
+
+const char* mi355rt_last_error(const mi355rt_handle* h) { return h ? h->r->last_error.c_str() : g_create_error.c_str(); }
+
+uint32_t mi355rt_trace_frame_additive(mi355rt_handle* h) { return h ? h->r->trace_frame_additive() : 0u; }
+
+int mi355rt_render(mi355rt_handle* h, uint32_t spp, mi355rt_ray_counts* counts)
+{
+    if (!h) return MI355RT_E_INVALID;
+    bool ok = h->r->render(spp);
+    if (counts) *counts = h->r->counts;
+    return ok ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+int mi355rt_last_counts(const mi355rt_handle* h, mi355rt_ray_counts* counts)
+{
+    if (!h || !counts) return MI355RT_E_INVALID;
+    *counts = h->r->counts;
+    return MI355RT_OK;
+}
+
+int mi355rt_get_tonemapped_pixels(mi355rt_handle* h, uint32_t* out, size_t n)
+{
+    if (!h) return MI355RT_E_INVALID;
+    return h->r->get_tonemapped(out, n) ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+int mi355rt_tonemap_owned_rows_device(mi355rt_handle* h, uint32_t* device_out, size_t n)
+{
+    if (!h) return MI355RT_E_INVALID;
+    return h->r->tonemap_owned_rows_device(device_out, n) ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+uint32_t mi355rt_owned_rows(const mi355rt_handle* h) { return h ? (uint32_t)h->r->owned_rows.size() : 0u; }
+
+int mi355rt_owned_row_list(const mi355rt_handle* h, uint32_t* rows, size_t n)
+{
+    if (!h || !rows || n < h->r->owned_rows.size()) return MI355RT_E_INVALID;
+    std::memcpy(rows, h->r->owned_rows.data(), h->r->owned_rows.size() * 4);
+    return MI355RT_OK;
+}
+
+int mi355rt_film_get(mi355rt_handle* h, float* sum_rgb, float* sumsq_rgb, uint32_t* n)
+{
+    if (!h) return MI355RT_E_INVALID;
+    return h->r->film_get(sum_rgb, sumsq_rgb, n) ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+int mi355rt_film_clear(mi355rt_handle* h)
+{
+    if (!h) return MI355RT_E_INVALID;
+    return h->r->film_clear() ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+int mi355rt_film_get_pixels(mi355rt_handle* h, float* rgb)
+{
+    if (!h || !rgb) return MI355RT_E_INVALID;
+    const size_t npix = (size_t)h->r->cfg.width * h->r->cfg.height;
+    std::vector<float> sum(npix * 3); std::vector<uint32_t> n(npix);
+    if (!h->r->film_get(sum.data(), nullptr, n.data())) return MI355RT_E_HIP;
+    for (size_t i = 0; i < npix; ++i) {
+        float inv = 1.0f / (float)n[i];                                          // film.rs:46
+        rgb[3 * i] = sum[3 * i] * inv; rgb[3 * i + 1] = sum[3 * i + 1] * inv; rgb[3 * i + 2] = sum[3 * i + 2] * inv;
+    }
+    return MI355RT_OK;
+}
+
+int mi355rt_film_get_estimated_variances(mi355rt_handle* h, float* rgb)
+{
+    if (!h || !rgb) return MI355RT_E_INVALID;
+    const size_t npix = (size_t)h->r->cfg.width * h->r->cfg.height;
+    std::vector<float> sum(npix * 3), sumsq(npix * 3); std::vector<uint32_t> n(npix);
+    if (!h->r->film_get(sum.data(), sumsq.data(), n.data())) return MI355RT_E_HIP;
+    for (size_t i = 0; i < npix; ++i) {                                          // film.rs:51-67
+        float nn1 = (float)(uint32_t)(n[i] * (n[i] - 1u));
+        float n2n1 = (float)n[i] * nn1;
+        for (int c = 0; c < 3; ++c)
+            rgb[3 * i + c] = (sumsq[3 * i + c] / nn1 - sum[3 * i + c] * sum[3 * i + c] / n2n1) * 50.0f;
+    }
+    return MI355RT_OK;
+}
+
+int mi355rt_camera_move_rel(mi355rt_handle* h, float x, float y, float z)
+{
+    if (!h) return MI355RT_E_INVALID;
+    h->r->camera.move_rel(x, y, z);
+    return MI355RT_OK;
+}
+int mi355rt_camera_add_x_angle(mi355rt_handle* h, float radians)
+{
+    if (!h) return MI355RT_E_INVALID;
+    h->r->camera.add_x_angle(radians);
+    return MI355RT_OK;
+}
+int mi355rt_camera_add_y_angle(mi355rt_handle* h, float radians)
+{
+    if (!h) return MI355RT_E_INVALID;
+    h->r->camera.add_y_angle(radians);
+    return MI355RT_OK;
+}
+int mi355rt_camera_get(const mi355rt_handle* h, float rot16[16], float orient16[16], float max_xy[2])
+{
+    if (!h) return MI355RT_E_INVALID;
+    if (rot16) std::memcpy(rot16, h->r->camera.rotation().e, 64);
+    if (orient16) std::memcpy(orient16, h->r->camera.orientation().e, 64);
+    if (max_xy) { max_xy[0] = h->r->camera.max_x(); max_xy[1] = h->r->camera.max_y(); }
+    return MI355RT_OK;
+}
+int mi355rt_camera_get_ray(const mi355rt_handle* h, uint32_t u, uint32_t v, float xi1, float xi2, float ray6[6])
+{
+    if (!h || !ray6) return MI355RT_E_INVALID;
+    Ray r = h->r->camera.get_ray(u, v, xi1, xi2);
+    ray6[0] = r.pos.x; ray6[1] = r.pos.y; ray6[2] = r.pos.z; ray6[3] = r.dir.x; ray6[4] = r.dir.y; ray6[5] = r.dir.z;
+    return MI355RT_OK;
+}
+
+int mi355rt_set_seed(mi355rt_handle* h, uint64_t seed)
+{
+    if (!h) return MI355RT_E_INVALID;
+    h->r->cfg.seed = seed;
+    return MI355RT_OK;
+}
+int mi355rt_set_flags(mi355rt_handle* h, uint32_t flags)
+{
+    if (!h) return MI355RT_E_INVALID;
+    h->r->cfg.flags = flags;
+    return MI355RT_OK;
+}
+
+int mi355rt_intersect_rays(mi355rt_handle* h, const float* rays6, size_t n, float* tuv, uint32_t* prim)
+{
+    if (!h || (n && (!rays6 || !tuv || !prim))) return MI355RT_E_INVALID;
+    return h->r->intersect(rays6, n, tuv, prim, nullptr) ? MI355RT_OK : MI355RT_E_HIP;
+}
+int mi355rt_occluded_rays(mi355rt_handle* h, const float* rays6, size_t n, uint8_t* blocked)
+{
+    if (!h || (n && (!rays6 || !blocked))) return MI355RT_E_INVALID;
+    return h->r->intersect(rays6, n, nullptr, nullptr, blocked) ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+int mi355rt_get_sample_table(const mi355rt_handle* h, float* out)
+{
+    if (!h || !out) return MI355RT_E_INVALID;
+    std::memcpy(out, h->r->table.data(), h->r->table.size() * sizeof(float));
+    return MI355RT_OK;
+}
+
+int mi355rt_debug_sample(mi355rt_handle* h, uint32_t pixel, uint32_t sampleno, float color3[3], float* node_L, size_t nodes)
+{
+    if (!h || !color3 || !node_L) return MI355RT_E_INVALID;
+    return h->r->debug_sample(pixel, sampleno, color3, node_L, nodes) ? MI355RT_OK : MI355RT_E_HIP;
+}
+uint32_t mi355rt_tree_nodes(const mi355rt_handle* h) { return h ? h->r->nodes_per_sample : 0u; }
+
+int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8])
+{
+    if (!h || !out) return MI355RT_E_INVALID;
+    const Bvh& b = h->r->bvh;
+    out[0] = (uint32_t)b.nodes.size(); out[1] = b.leaves; out[2] = b.max_depth; out[3] = b.max_leaf;
+    out[4] = (uint32_t)(b.nodes.size() * sizeof(BvhNode)); out[5] = (uint32_t)(b.tris.size() * sizeof(BvhTri));
+    out[6] = 0; out[7] = 0;
+    return MI355RT_OK;
+}
+uint32_t mi355rt_width(const mi355rt_handle* h) { return h ? h->r->cfg.width : 0u; }
+uint32_t mi355rt_height(const mi355rt_handle* h) { return h ? h->r->cfg.height : 0u; }
+uint32_t mi355rt_triangle_count(const mi355rt_handle* h) { return h ? h->r->ntri : 0u; }
+uint32_t mi355rt_current_row(const mi355rt_handle* h) { return h ? h->r->current_row : 0u; }
+
+}  // extern "C"

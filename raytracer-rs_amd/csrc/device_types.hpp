@@ -1,0 +1,66 @@
+// device_types.hpp — plain structs shared by the host renderer and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace mi355rt {
+
+constexpr uint32_t kNumSamples = 65536;     // sample_generator.rs:5-7
+constexpr uint32_t kSampleMax = 65535;
+constexpr uint32_t kMaxRecursions = 3;
+constexpr uint32_t kMaxLevels = kMaxRecursions + 1;
+
+// Ray-queue record, 48 bytes = 3 x float4:
+//   q0 = (o.x, o.y, o.z, d.x)   q1 = (d.y, d.z, slot, meta)
+//   q2 = radiance ray: (pixel, sample#, -, -) as bits;  shadow ray: (L.r, L.g, L.b, -)
+// meta: bit 0 kind (0 radiance, 1 shadow) | level << 4 | node << 8 | light << 24
+constexpr uint32_t kRayRecordBytes = 48;
+
+struct DMaterial { float r, g, b; uint32_t kind_tex; };       // kind_tex: bit 31 = texture, low bits = texture id
+struct DLight { float px, py, pz, cr, cg, cb; };
+struct DTexture { uint32_t width, height; uint64_t offset; }; // offset in texels into the texel pool
+
+struct DScene {
+    const void* nodes;        // BvhNode[]
+    const void* tris;         // BvhTri[] (leaf order)
+    const void* normals;      // float4[ntri]: (n.xyz, geometry index bits), original triangle order
+    const DMaterial* materials;
+    const DLight* lights;
+    const DTexture* textures;
+    const float* texels;      // RGB f32 pool
+    const void* table;        // float4[65536] unit vectors
+    int32_t root;
+    uint32_t nlights;
+    uint32_t ntri;
+    uint32_t lds_nodes;       // nodes [0, lds_nodes) are staged in LDS by the trace kernel
+};
+
+struct DCamera {
+    float rot[16];            // rotation_matrix, camera.rs:92-95
+    float origin[3];          // orientation_matrix * (0,0,0,1)
+    float max_x, max_y;
+    uint32_t width, height;
+};
+
+struct DPass {
+    // primary-sample enumeration: thread i -> s = i / npix, p = i % npix,
+    // row = rows[row0 + p / width], x = p % width, pixel = row * width + x
+    const uint32_t* rows;
+    uint32_t row0;
+    uint32_t npix;            // pixels in this pass (rows_in_pass * width)
+    uint32_t nsamples;        // npix * samples per pixel in this pass
+    uint32_t seed;
+    uint32_t flags;
+    uint32_t recursions, spread;
+    uint32_t nodes_per_sample;
+    uint32_t level_first[kMaxLevels + 1];
+    uint32_t use_explicit, explicit_pixel, explicit_sampleno;
+    uint32_t out_capacity;    // records
+};
+
+struct DCounters {            // one set per render call, zeroed at its start
+    unsigned long long bounce, shadow, primary_hits, nodes_visited, tris_tested;
+    unsigned int overflow;
+    unsigned int pad;
+};
+
+}  // namespace mi355rt

@@ -1,0 +1,428 @@
+// renderer.cpp — see renderer.hpp.
+#include "renderer.hpp"
+#include <algorithm>
+#include <cstring>
+#include "kernels.hpp"
+
+namespace mi355rt {
+
+namespace {
+// counter RNG, identical to the device copy in kernels.hip (pcg4d, Jarzynski & Olano 2020)
+void pcg4d(uint32_t v[4])
+{
+    for (int i = 0; i < 4; ++i) v[i] = v[i] * 1664525u + 1013904223u;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+    for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+}
+float u01(uint32_t bits) { return (float)(bits >> 9) * (1.0f / 8388608.0f); }
+}  // namespace
+
+bool Renderer::fail(hipError_t e, const char* what)
+{
+    last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(e__, #expr); } while (0)
+
+bool Renderer::bind()
+{
+    HIP_TRY(hipSetDevice(cfg.device));
+    return true;
+}
+
+template <class T> bool Renderer::upload(T*& dptr, const void* src, size_t bytes)
+{
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+    allocs_.push_back(p);
+    if (bytes && src) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    else if (bytes) HIP_TRY(hipMemset(p, 0, bytes));
+    dptr = static_cast<T*>(p);
+    return true;
+}
+
+std::unique_ptr<Renderer> Renderer::create(const SceneData& scene, const mi355rt_config& cfg, std::string& err, int& code)
+{
+    std::unique_ptr<Renderer> r(new Renderer());
+    r->cfg = cfg;
+    if (!r->init(scene, err, code)) return nullptr;
+    return r;
+}
+
+bool Renderer::init(const SceneData& scene, std::string& err, int& code)
+{
+    code = MI355RT_E_INVALID;
+    if (cfg.recursions == 0 && cfg.spread == 0) { cfg.recursions = 2; cfg.spread = 1; }   // RECURSIONS / SUB_SPREAD, mod.rs:81-82
+    if (cfg.spread == 0) cfg.spread = 1;
+    if (cfg.triangles_per_leaf == 0) cfg.triangles_per_leaf = MI355RT_DEFAULT_TRIANGLES_PER_LEAF;
+    if (cfg.width == 0 || cfg.height == 0) { err = "width and height must be non-zero"; return false; }
+    if ((uint64_t)cfg.width * cfg.height > 0x7FFFFFFFull / 4) { err = "image too large"; return false; }
+    if (cfg.recursions > kMaxRecursions) { err = "recursions > 3 not supported"; return false; }
+    if (scene.cameras.empty()) { err = "scene has no camera"; return false; }     // scene.cameras[0] panics in the reference, lib.rs:39
+    if (scene.tri_geom.size() * 9 != scene.tri_verts.size()) { err = "tri_verts / tri_geom size mismatch"; return false; }
+    for (uint32_t g : scene.tri_geom) if (g >= scene.materials.size()) { err = "tri_geom entry out of range"; return false; }
+    for (auto& m : scene.materials) if (m.kind == 1 && m.tex_id >= scene.textures.size()) { err = "material texture id out of range"; return false; }
+    if (scene.tri_geom.size() >= (1u << 28)) { err = "too many triangles"; return false; }
+    {   // radiance tree: level l has prod_{j<l} spread*(recursions-j) nodes
+        uint64_t count = 1, first = 0;
+        for (uint32_t l = 0; l <= cfg.recursions; ++l) {
+            level_first[l] = (uint32_t)first; first += count; count *= (uint64_t)cfg.spread * (cfg.recursions - l);
+            if (first > 0xFFFF) { err = "radiance tree too large (spread * recursions)"; return false; }
+        }
+        for (uint32_t l = cfg.recursions + 1; l <= kMaxLevels; ++l) level_first[l] = (uint32_t)first;
+        nodes_per_sample = (uint32_t)first;
+    }
+    if (cfg.stripe_world <= 1) { cfg.stripe_world = 1; cfg.stripe_rank = 0; }
+    if (cfg.stripe_rows == 0) cfg.stripe_rows = 8;
+    if (cfg.stripe_rank >= cfg.stripe_world) { err = "stripe_rank >= stripe_world"; return false; }
+
+    code = MI355RT_E_NO_DEVICE;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { err = std::string("no HIP device available (") + hipGetErrorString(e) + "); this library has no CPU fallback"; return false; }
+    if (cfg.device < 0 || cfg.device >= ndev) { err = "HIP device ordinal out of range"; return false; }
+    auto bail = [&]() { err = last_error; return false; };
+    if (!bind()) return bail();
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg.device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return false; }
+    num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+    if (hipEventCreate(&ev_begin_) != hipSuccess || hipEventCreate(&ev_end_) != hipSuccess) { err = "hipEventCreate failed"; return false; }
+
+    ntri = scene.ntri();
+    nlights_ = (uint32_t)scene.lights.size();
+    camera = Camera::from_orientation_matrix(cfg.width, cfg.height, Matrix::from_array(scene.cameras[0].orientation), scene.cameras[0].fov_deg);
+
+    // --- acceleration structure (host build, once) + per-triangle normals (calc_normal, mod.rs:198-205)
+    build_bvh(scene.tri_verts.data(), scene.tri_geom.data(), ntri, bvh);
+    if (bvh.max_depth > kBvhMaxDepth) { err = "internal: BVH deeper than the traversal stack"; code = MI355RT_E_INVALID; return false; }
+    std::vector<float> normals((size_t)std::max(ntri, 1u) * 4, 0.0f);
+    for (uint32_t t = 0; t < ntri; ++t) {
+        const float* v = &scene.tri_verts[9 * (size_t)t];
+        Vec3 v0(v[0], v[1], v[2]), v1(v[3], v[4], v[5]), v2(v[6], v[7], v[8]);
+        Vec3 n = cross(v1 - v0, v2 - v0).normalized();
+        normals[4 * (size_t)t] = n.x; normals[4 * (size_t)t + 1] = n.y; normals[4 * (size_t)t + 2] = n.z;
+        uint32_t g = scene.tri_geom[t];
+        std::memcpy(&normals[4 * (size_t)t + 3], &g, 4);
+    }
+    // --- SampleGenerator::new, sample_generator.rs:15-24 + 36-52, seeded
+    table.resize((size_t)kNumSamples * 3);
+    std::vector<float> table4((size_t)kNumSamples * 4, 0.0f);
+    for (uint32_t i = 0; i < kNumSamples; ++i) {
+        for (uint32_t attempt = 0;; ++attempt) {
+            uint32_t h[4] = { i, attempt, 0xFFFFFFFFu, (uint32_t)cfg.seed };
+            pcg4d(h);
+            Vec3 d(u01(h[0]) * 2.0f + -1.0f, u01(h[1]) * 2.0f + -1.0f, u01(h[2]) * 2.0f + -1.0f);   // random_range(-1.0..1.0)
+            if (dot(d, d) < 1.0f) {
+                Vec3 nrm = d.normalized();
+                table[3 * (size_t)i] = nrm.x; table[3 * (size_t)i + 1] = nrm.y; table[3 * (size_t)i + 2] = nrm.z;
+                table4[4 * (size_t)i] = nrm.x; table4[4 * (size_t)i + 1] = nrm.y; table4[4 * (size_t)i + 2] = nrm.z;
+                break;
+            }
+        }
+    }
+    // --- uploads
+    void* d_nodes = nullptr; void* d_tris = nullptr; void* d_normals = nullptr; void* d_table = nullptr;
+    DMaterial* d_mats = nullptr; DLight* d_lights = nullptr; DTexture* d_tex = nullptr; float* d_texels = nullptr;
+    if (!upload(d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode))) return bail();
+    if (!upload(d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri))) return bail();
+    if (!upload(d_normals, normals.data(), normals.size() * sizeof(float))) return bail();
+    if (!upload(d_table, table4.data(), table4.size() * sizeof(float))) return bail();
+    std::vector<DMaterial> mats(std::max<size_t>(scene.materials.size(), 1));
+    for (size_t i = 0; i < scene.materials.size(); ++i) {
+        const MaterialData& m = scene.materials[i];
+        mats[i] = DMaterial{ m.rgb[0], m.rgb[1], m.rgb[2], m.kind == 1 ? (0x80000000u | m.tex_id) : 0u };
+    }
+    if (!upload(d_mats, mats.data(), mats.size() * sizeof(DMaterial))) return bail();
+    std::vector<DLight> lights(std::max<size_t>(scene.lights.size(), 1));
+    for (size_t i = 0; i < scene.lights.size(); ++i) {
+        const LightData& l = scene.lights[i];
+        lights[i] = DLight{ l.pos[0], l.pos[1], l.pos[2], l.color[0], l.color[1], l.color[2] };
+    }
+    if (!upload(d_lights, lights.data(), lights.size() * sizeof(DLight))) return bail();
+    std::vector<DTexture> tex(std::max<size_t>(scene.textures.size(), 1));
+    std::vector<float> texels;
+    for (size_t i = 0; i < scene.textures.size(); ++i) {
+        const TextureData& t = scene.textures[i];
+        if (t.rgb.size() != (size_t)t.width * t.height * 3 || t.rgb.empty()) { err = "texture size mismatch"; code = MI355RT_E_INVALID; return false; }
+        tex[i] = DTexture{ t.width, t.height, texels.size() / 3 };
+        texels.insert(texels.end(), t.rgb.begin(), t.rgb.end());
+    }
+    if (!upload(d_tex, tex.data(), tex.size() * sizeof(DTexture))) return bail();
+    if (!upload(d_texels, texels.data(), texels.size() * sizeof(float))) return bail();
+    dscene_.nodes = d_nodes; dscene_.tris = d_tris; dscene_.normals = d_normals; dscene_.materials = d_mats;
+    dscene_.lights = d_lights; dscene_.textures = d_tex; dscene_.texels = d_texels; dscene_.table = d_table;
+    dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri; dscene_.lds_nodes = 0;
+
+    // --- film (film.rs:27-35) and row lists
+    const size_t npix = (size_t)cfg.width * cfg.height;
+    if (!upload(d_film_sum_, nullptr, npix * 12) || !upload(d_film_sumsq_, nullptr, npix * 12) || !upload(d_film_n_, nullptr, npix * 4)) return bail();
+    if (!upload(d_ldr_, nullptr, npix * 4)) return bail();
+    std::vector<uint32_t> all(cfg.height);
+    for (uint32_t r = 0; r < cfg.height; ++r) {
+        all[r] = r;
+        if ((r / cfg.stripe_rows) % cfg.stripe_world == cfg.stripe_rank) owned_rows.push_back(r);
+    }
+    if (!upload(d_all_rows_, all.data(), all.size() * 4)) return bail();
+    if (!upload(d_owned_rows_, owned_rows.data(), owned_rows.size() * 4)) return bail();
+    if (!upload(d_tmp_rows_, nullptr, 64 * 4)) return bail();
+    if (!upload(d_counters_, nullptr, sizeof(DCounters))) return bail();
+    if (!upload(d_ctrl_, nullptr, 16 * 4)) return bail();
+    if (!upload(d_debug_color_, nullptr, 16)) return bail();
+
+    // queue records one sample can put into one round's output queue (shadow rays of level l + rays of level l+1)
+    records_per_sample_ = 1;
+    for (uint32_t l = 0; l <= cfg.recursions; ++l) {
+        uint32_t nl = level_first[l + 1] - level_first[l];
+        uint32_t nn = l < cfg.recursions ? level_first[l + 2] - level_first[l + 1] : 0;
+        records_per_sample_ = std::max(records_per_sample_, nl * std::max(nlights_, 1u) + nn);
+    }
+    code = MI355RT_OK;
+    return true;
+}
+
+Renderer::~Renderer()
+{
+    if (hipSetDevice(cfg.device) != hipSuccess) return;
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (void* p : allocs_) (void)hipFree(p);
+    if (d_queue_[0]) (void)hipFree(d_queue_[0]);
+    if (d_queue_[1]) (void)hipFree(d_queue_[1]);
+    if (d_slot_L_) (void)hipFree(d_slot_L_);
+    for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
+    if (ev_begin_) (void)hipEventDestroy(ev_begin_);
+    if (ev_end_) (void)hipEventDestroy(ev_end_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+DCamera Renderer::device_camera() const
+{
+    DCamera c;
+    std::memcpy(c.rot, camera.rotation().e, sizeof c.rot);
+    Vec4 pos = camera.orientation() * Vec4(0.0f, 0.0f, 0.0f, 1.0f);      // camera.rs:88
+    c.origin[0] = pos.x; c.origin[1] = pos.y; c.origin[2] = pos.z;
+    c.max_x = camera.max_x(); c.max_y = camera.max_y();
+    c.width = cfg.width; c.height = cfg.height;
+    return c;
+}
+
+bool Renderer::ensure_pass_capacity(size_t nsamples)
+{
+    if (nsamples <= pass_capacity_) return true;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int i = 0; i < 2; ++i) if (d_queue_[i]) { (void)hipFree(d_queue_[i]); d_queue_[i] = nullptr; }
+    if (d_slot_L_) { (void)hipFree(d_slot_L_); d_slot_L_ = nullptr; }
+    pass_capacity_ = 0;
+    size_t records = nsamples * records_per_sample_;
+    if (records > 0x7FFFFFFFull) { last_error = "pass too large"; return false; }
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc(&d_queue_[i], records * kRayRecordBytes));
+    HIP_TRY(hipMalloc((void**)&d_slot_L_, nsamples * nodes_per_sample * std::max(nlights_, 1u) * 12));
+    pass_capacity_ = nsamples;
+    queue_records_ = records;
+    return true;
+}
+
+// One wavefront pass: `nrows` rows starting at d_rows[row0], spp samples per pixel.
+bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample)
+{
+    const uint32_t npix = explicit_sample ? 1u : nrows * cfg.width;
+    const size_t nsamples = (size_t)npix * spp;
+    if (nsamples == 0) return true;
+    if (!ensure_pass_capacity(nsamples)) return false;
+    DPass ps{};
+    ps.rows = d_rows; ps.row0 = row0; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
+    ps.seed = (uint32_t)cfg.seed; ps.flags = cfg.flags; ps.recursions = cfg.recursions; ps.spread = cfg.spread;
+    ps.nodes_per_sample = nodes_per_sample;
+    std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
+    ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
+    ps.out_capacity = (uint32_t)queue_records_;
+    const DCamera cam = device_camera();
+    const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
+    const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
+
+    HIP_TRY(hipMemsetAsync(d_slot_L_, 0, nsamples * nodes_per_sample * std::max(nlights_, 1u) * 12, stream_));
+    HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 16 * 4, stream_));
+    const uint32_t rounds = cfg.recursions + 2;      // levels 0..R, plus the shadow rays of level R
+    for (uint32_t r = 0; r < rounds; ++r) {
+        if (timed) {
+            if (ev_used_ + 2 > ev_pool_.size()) {
+                for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); ev_pool_.push_back(ev); }
+            }
+            HIP_TRY(hipEventRecord(ev_pool_[ev_used_], stream_));
+        }
+        HIP_TRY(launch_trace_round(stream_, num_cus_, r == 0, count, dscene_, cam, ps, r,
+                                   r == 0 ? nullptr : d_queue_[(r - 1) & 1], d_ctrl_ + 8 + r, d_queue_[r & 1], d_ctrl_ + 8 + r + 1, d_ctrl_ + r,
+                                   d_slot_L_, d_film_n_, d_counters_));
+        if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], stream_)); ev_used_ += 2; }
+        ++launches_;
+    }
+    HIP_TRY(launch_resolve(stream_, ps, cfg.width, nlights_, d_slot_L_, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
+    return true;
+}
+
+bool Renderer::begin_call()
+{
+    if (!bind()) return false;
+    ev_used_ = 0; launches_ = 0;
+    HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters), stream_));
+    HIP_TRY(hipEventRecord(ev_begin_, stream_));
+    return true;
+}
+
+bool Renderer::end_call(uint64_t primary)
+{
+    HIP_TRY(hipEventRecord(ev_end_, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    DCounters c;
+    HIP_TRY(hipMemcpy(&c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
+    counts = mi355rt_ray_counts{};
+    counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
+    counts.nodes_visited = c.nodes_visited; counts.tris_tested = c.tris_tested; counts.trace_launches = launches_;
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+    counts.total_ms = ms;
+    double tms = 0.0;
+    for (size_t i = 0; i + 1 < ev_used_; i += 2) {
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, ev_pool_[i], ev_pool_[i + 1]));
+        tms += t;
+    }
+    counts.trace_ms = tms;
+    if (c.overflow) { last_error = "internal: ray queue overflow"; return false; }
+    return true;
+}
+
+uint32_t Renderer::trace_frame_additive()
+{
+    if (!begin_call()) return 0;
+    // 50 rows from the row cursor, wrapping modulo height (mod.rs:87,114); with stripes only owned rows are traced
+    std::vector<uint32_t> rows;
+    uint32_t row = current_row;
+    for (int k = 0; k < 50; ++k) {
+        if ((row / cfg.stripe_rows) % cfg.stripe_world == cfg.stripe_rank) rows.push_back(row);
+        row = (row + 1) % cfg.height;
+    }
+    // a row can appear more than once when height < 50: each occurrence is its own 1-sample pass segment
+    size_t start = 0;
+    while (start < rows.size()) {
+        size_t end = start + 1;
+        while (end < rows.size() && std::find(rows.begin() + start, rows.begin() + end, rows[end]) == rows.begin() + end) ++end;
+        if (hipMemcpyAsync(d_tmp_rows_, rows.data() + start, (end - start) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "row upload failed"; return 0; }
+        if (hipStreamSynchronize(stream_) != hipSuccess) { last_error = "stream sync failed"; return 0; }
+        if (!run_pass(d_tmp_rows_, 0, (uint32_t)(end - start), 1, false, 0, 0)) return 0;
+        start = end;
+    }
+    current_row = row;
+    if (!end_call((uint64_t)rows.size() * cfg.width)) return 0;
+    return 50u * cfg.width;
+}
+
+bool Renderer::render(uint32_t spp)
+{
+    if (!begin_call()) return false;
+    const uint32_t nrows = (uint32_t)owned_rows.size();
+    if (nrows && spp) {
+        const size_t target = cfg.samples_per_pass ? (size_t)cfg.samples_per_pass * cfg.width * nrows : ((size_t)8 << 20);
+        uint32_t rows_per_pass = (uint32_t)std::min<size_t>(nrows, std::max<size_t>(1, target / cfg.width));
+        uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, target / ((size_t)rows_per_pass * cfg.width)));
+        if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
+        for (uint32_t done = 0; done < spp; done += k) {
+            const uint32_t kk = std::min(k, spp - done);
+            for (uint32_t r0 = 0; r0 < nrows; r0 += rows_per_pass)
+                if (!run_pass(d_owned_rows_, r0, std::min(rows_per_pass, nrows - r0), kk, false, 0, 0)) return false;
+        }
+    }
+    return end_call((uint64_t)nrows * cfg.width * spp);
+}
+
+bool Renderer::get_tonemapped(uint32_t* out, size_t n)
+{
+    if (!bind()) return false;
+    const size_t npix = (size_t)cfg.width * cfg.height;
+    if (n < npix || !out) { last_error = "output buffer too small"; return false; }
+    HIP_TRY(launch_tonemap(stream_, d_all_rows_, cfg.height, cfg.width, false, d_film_sum_, d_film_n_, d_ldr_));
+    HIP_TRY(hipMemcpyAsync(out, d_ldr_, npix * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return true;
+}
+
+bool Renderer::tonemap_owned_rows_device(uint32_t* device_out, size_t n)
+{
+    if (!bind()) return false;
+    if (n < owned_rows.size() * (size_t)cfg.width || !device_out) { last_error = "output buffer too small"; return false; }
+    HIP_TRY(launch_tonemap(stream_, d_owned_rows_, (uint32_t)owned_rows.size(), cfg.width, true, d_film_sum_, d_film_n_, device_out));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return true;
+}
+
+bool Renderer::film_get(float* sum, float* sumsq, uint32_t* n)
+{
+    if (!bind()) return false;
+    const size_t npix = (size_t)cfg.width * cfg.height;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (sum) HIP_TRY(hipMemcpy(sum, d_film_sum_, npix * 12, hipMemcpyDeviceToHost));
+    if (sumsq) HIP_TRY(hipMemcpy(sumsq, d_film_sumsq_, npix * 12, hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy(n, d_film_n_, npix * 4, hipMemcpyDeviceToHost));
+    return true;
+}
+
+bool Renderer::film_clear()
+{
+    if (!bind()) return false;
+    const size_t npix = (size_t)cfg.width * cfg.height;
+    HIP_TRY(hipMemsetAsync(d_film_sum_, 0, npix * 12, stream_));
+    HIP_TRY(hipMemsetAsync(d_film_sumsq_, 0, npix * 12, stream_));
+    HIP_TRY(hipMemsetAsync(d_film_n_, 0, npix * 4, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return true;
+}
+
+bool Renderer::intersect(const float* rays6, size_t n, float* tuv, uint32_t* prim, uint8_t* blocked)
+{
+    if (!bind()) return false;
+    if (n == 0) return true;
+    if (n > 0x7FFFFFFFull / 24) { last_error = "too many rays in one batch"; return false; }
+    const bool shadow = blocked != nullptr;
+    float* d_rays = nullptr; float* d_tuv = nullptr; uint32_t* d_prim = nullptr; uint8_t* d_blocked = nullptr;
+    bool ok = true;
+    auto chk = [&](hipError_t e, const char* w) { if (ok && e != hipSuccess) { ok = fail(e, w); } };
+    chk(hipMalloc((void**)&d_rays, n * 24), "hipMalloc rays");
+    chk(hipMalloc((void**)&d_tuv, n * 12), "hipMalloc tuv");
+    chk(hipMalloc((void**)&d_prim, n * 4), "hipMalloc prim");
+    chk(hipMalloc((void**)&d_blocked, n), "hipMalloc blocked");
+    if (ok) chk(hipMemcpyAsync(d_rays, rays6, n * 24, hipMemcpyHostToDevice, stream_), "upload rays");
+    if (ok && !shadow) chk(hipMemcpyAsync(d_tuv, tuv, n * 12, hipMemcpyHostToDevice, stream_), "upload tuv");   // misses stay untouched
+    if (ok) chk(launch_intersect(stream_, dscene_, d_rays, (uint32_t)n, shadow, d_tuv, d_prim, d_blocked), "intersect kernel");
+    if (ok && shadow) chk(hipMemcpyAsync(blocked, d_blocked, n, hipMemcpyDeviceToHost, stream_), "download blocked");
+    if (ok && !shadow) {
+        chk(hipMemcpyAsync(tuv, d_tuv, n * 12, hipMemcpyDeviceToHost, stream_), "download tuv");
+        chk(hipMemcpyAsync(prim, d_prim, n * 4, hipMemcpyDeviceToHost, stream_), "download prim");
+    }
+    if (ok) chk(hipStreamSynchronize(stream_), "sync");
+    (void)hipFree(d_rays); (void)hipFree(d_tuv); (void)hipFree(d_prim); (void)hipFree(d_blocked);
+    return ok;
+}
+
+bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, float* node_L, size_t nodes)
+{
+    if (!bind()) return false;
+    if (nodes < nodes_per_sample || pixel >= cfg.width * cfg.height) { last_error = "bad debug_sample arguments"; return false; }
+    HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters), stream_));
+    ev_used_ = 0;
+    if (!run_pass(nullptr, 0, 1, 1, true, pixel, sampleno)) return false;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    const uint32_t nl = std::max(nlights_, 1u);
+    std::vector<float> raw((size_t)nodes_per_sample * nl * 3);
+    HIP_TRY(hipMemcpy(raw.data(), d_slot_L_, raw.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(color3, d_debug_color_, 12, hipMemcpyDeviceToHost));
+    for (uint32_t nd = 0; nd < nodes_per_sample; ++nd) {
+        float acc[3] = { 0.0f, 0.0f, 0.0f };
+        for (uint32_t li = 0; li < nlights_; ++li)
+            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + raw[3 * ((size_t)nd * nl + li) + c];
+        node_L[3 * nd] = acc[0]; node_L[3 * nd + 1] = acc[1]; node_L[3 * nd + 2] = acc[2];
+    }
+    return true;
+}
+
+}  // namespace mi355rt

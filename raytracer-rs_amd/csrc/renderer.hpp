@@ -1,0 +1,77 @@
+// renderer.hpp — host side of the device render path: owns the HIP buffers, the camera and the
+// film of one RayTracer (raytracer/mod.rs:32-47) and schedules the wavefront passes.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/mi355rt.h"
+#include "bvh.hpp"
+#include "camera.hpp"
+#include "device_types.hpp"
+#include "scene.hpp"
+
+namespace mi355rt {
+
+class Renderer {
+public:
+    static std::unique_ptr<Renderer> create(const SceneData& scene, const mi355rt_config& cfg, std::string& err, int& code);
+    ~Renderer();
+
+    uint32_t trace_frame_additive();                                   // mod.rs:80-117
+    bool render(uint32_t spp);
+    bool get_tonemapped(uint32_t* out, size_t n);                       // mod.rs:120-128
+    bool tonemap_owned_rows_device(uint32_t* device_out, size_t n);
+    bool film_get(float* sum, float* sumsq, uint32_t* n);
+    bool film_clear();                                                  // film.rs:37-41
+    bool intersect(const float* rays6, size_t n, float* tuv, uint32_t* prim, uint8_t* blocked);
+    bool debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, float* node_L, size_t nodes);
+
+    Camera camera;
+    mi355rt_config cfg;
+    mi355rt_ray_counts counts{};
+    std::string last_error;
+    std::vector<float> table;            // 65536 x 3
+    std::vector<uint32_t> owned_rows;
+    Bvh bvh;
+    uint32_t ntri = 0;
+    uint32_t current_row = 0;
+    uint32_t nodes_per_sample = 1;
+    uint32_t level_first[kMaxLevels + 1] = { 0 };
+
+private:
+    Renderer() = default;
+    bool init(const SceneData& scene, std::string& err, int& code);
+    bool bind();
+    bool fail(hipError_t e, const char* what);
+    bool ensure_pass_capacity(size_t nsamples);
+    bool run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample);
+    bool begin_call();
+    bool end_call(uint64_t primary);
+    DCamera device_camera() const;
+    template <class T> bool upload(T*& dptr, const void* src, size_t bytes);
+
+    int num_cus_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
+    std::vector<hipEvent_t> ev_pool_;
+    size_t ev_used_ = 0;
+    std::vector<void*> allocs_;
+
+    DScene dscene_{};
+    float* d_film_sum_ = nullptr; float* d_film_sumsq_ = nullptr; uint32_t* d_film_n_ = nullptr;
+    uint32_t* d_owned_rows_ = nullptr; uint32_t* d_all_rows_ = nullptr; uint32_t* d_tmp_rows_ = nullptr;
+    uint32_t* d_ldr_ = nullptr;
+    DCounters* d_counters_ = nullptr;
+    uint32_t* d_ctrl_ = nullptr;         // [0..7] cursors, [8..15] queue counts
+    float* d_debug_color_ = nullptr;
+    void* d_queue_[2] = { nullptr, nullptr };
+    float* d_slot_L_ = nullptr;
+    size_t pass_capacity_ = 0;           // samples
+    size_t queue_records_ = 0;
+    uint32_t records_per_sample_ = 1;
+    uint32_t nlights_ = 0;
+    uint64_t launches_ = 0;
+};
+
+}  // namespace mi355rt

@@ -1,0 +1,50 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+
+
+def _ensure_built():
+    pkg_lib = os.path.join(ROOT, "raytracer-rs_amd", "libmi355rt.so")
+    orc_lib = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(pkg_lib) and os.path.exists(orc_lib)):
+        ge.build()
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    _ensure_built()
+    return ge.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    _ensure_built()
+    return ge.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def scene_io(pkg):
+    import importlib
+    return importlib.import_module("raytracer_rs_amd.scene_io")
+
+
+@pytest.fixture(scope="session")
+def scenes(scene_io):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = scene_io.load_scene_file(os.path.join(SCENES, name + ".scene"))
+        return cache[name]
+    return get
