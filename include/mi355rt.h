@@ -177,6 +177,9 @@ int mi355rt_get_sample_table(const mi355rt_handle* h, float* out);
  * kernels as a frame (stage-level parity): node_L = nodes x 3 floats (breadth-first radiance
  * tree, black where not reached), color3 = the sample's radiance.  Does not touch the film. */
 int mi355rt_debug_sample(mi355rt_handle* h, uint32_t pixel, uint32_t sampleno, float color3[3], float* node_L, size_t nodes);
+/* Device arithmetic self-check: quot = a/b, root = sqrt(a), pow32 = a^32 computed exactly as the
+ * kernels compute them (IEEE division and square root; powf(x, 32.0) of mod.rs:255). */
+int mi355rt_debug_numerics(mi355rt_handle* h, const float* a, const float* b, size_t n, float* quot, float* root, float* pow32);
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
 
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,

@@ -113,6 +113,7 @@ ABI = [
     ("mi355rt_occluded_rays", C.c_int, [_H, _F, C.c_size_t, C.POINTER(C.c_uint8)]),
     ("mi355rt_get_sample_table", C.c_int, [_H, _F]),
     ("mi355rt_debug_sample", C.c_int, [_H, C.c_uint32, C.c_uint32, _F, _F, C.c_size_t]),
+    ("mi355rt_debug_numerics", C.c_int, [_H, _F, _F, C.c_size_t, _F, _F, _F]),
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
     ("mi355rt_width", C.c_uint32, [_H]),
@@ -300,6 +301,12 @@ class RayTracer:
         color = np.zeros(3, np.float32); node_l = np.zeros((nodes, 3), np.float32)
         self._check(lib().mi355rt_debug_sample(self._h, pixel, sampleno, _fp(color), _fp(node_l), nodes))
         return color, node_l
+
+    def debug_numerics(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        q = np.zeros_like(a); r = np.zeros_like(a); p = np.zeros_like(a)
+        self._check(lib().mi355rt_debug_numerics(self._h, _fp(a), _fp(b), a.size, _fp(q), _fp(r), _fp(p)))
+        return q, r, p
 
     def accel_stats(self):
         out = np.zeros(8, np.uint32)

@@ -251,6 +251,11 @@ int mi355rt_debug_sample(mi355rt_handle* h, uint32_t pixel, uint32_t sampleno, f
     if (!h || !color3 || !node_L) return MI355RT_E_INVALID;
     return h->r->debug_sample(pixel, sampleno, color3, node_L, nodes) ? MI355RT_OK : MI355RT_E_HIP;
 }
+int mi355rt_debug_numerics(mi355rt_handle* h, const float* a, const float* b, size_t n, float* quot, float* root, float* pow32)
+{
+    if (!h || (n && (!a || !b || !quot || !root || !pow32))) return MI355RT_E_INVALID;
+    return h->r->debug_numerics(a, b, n, quot, root, pow32) ? MI355RT_OK : MI355RT_E_HIP;
+}
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h) { return h ? h->r->nodes_per_sample : 0u; }
 
 int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8])

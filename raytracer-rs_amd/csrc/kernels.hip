@@ -440,6 +440,22 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(DScene sc, const floa
     }
 }
 
+// ---- device arithmetic self-check: a/b, sqrt(a), a^32 as the kernels compute them ----------------
+__global__ void numerics_kernel(const float* __restrict__ a, const float* __restrict__ b, uint32_t n, float* q, float* r, float* p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    q[i] = div_rn(a[i], b[i]);
+    r[i] = sqrt_rn(a[i]);
+    p[i] = pow32(a[i]);
+}
+hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, uint32_t n, float* q, float* r, float* p)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(numerics_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, b, n, q, r, p);
+    return hipGetLastError();
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 static int g_trace_blocks_per_cu[4] = { 0, 0, 0, 0 };
 

@@ -16,4 +16,6 @@ hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t nro
 hipError_t launch_intersect(hipStream_t stream, const DScene& sc, const float* rays6, uint32_t n, bool shadow_mode,
                             float* tuv, uint32_t* prim, uint8_t* blocked);
 
+hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, uint32_t n, float* q, float* r, float* p);
+
 }  // namespace mi355rt

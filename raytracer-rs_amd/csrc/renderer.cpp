@@ -404,6 +404,25 @@ bool Renderer::intersect(const float* rays6, size_t n, float* tuv, uint32_t* pri
     return ok;
 }
 
+bool Renderer::debug_numerics(const float* a, const float* b, size_t n, float* q, float* r, float* p)
+{
+    if (!bind()) return false;
+    if (n == 0) return true;
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, n * 4 * 5));
+    bool ok = true;
+    auto chk = [&](hipError_t e, const char* w) { if (ok && e != hipSuccess) ok = fail(e, w); };
+    chk(hipMemcpyAsync(d, a, n * 4, hipMemcpyHostToDevice, stream_), "upload a");
+    chk(hipMemcpyAsync(d + n, b, n * 4, hipMemcpyHostToDevice, stream_), "upload b");
+    if (ok) chk(launch_numerics(stream_, d, d + n, (uint32_t)n, d + 2 * n, d + 3 * n, d + 4 * n), "numerics kernel");
+    chk(hipMemcpyAsync(q, d + 2 * n, n * 4, hipMemcpyDeviceToHost, stream_), "download q");
+    chk(hipMemcpyAsync(r, d + 3 * n, n * 4, hipMemcpyDeviceToHost, stream_), "download r");
+    chk(hipMemcpyAsync(p, d + 4 * n, n * 4, hipMemcpyDeviceToHost, stream_), "download p");
+    chk(hipStreamSynchronize(stream_), "sync");
+    (void)hipFree(d);
+    return ok;
+}
+
 bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, float* node_L, size_t nodes)
 {
     if (!bind()) return false;

@@ -25,6 +25,7 @@ public:
     bool film_get(float* sum, float* sumsq, uint32_t* n);
     bool film_clear();                                                  // film.rs:37-41
     bool intersect(const float* rays6, size_t n, float* tuv, uint32_t* prim, uint8_t* blocked);
+    bool debug_numerics(const float* a, const float* b, size_t n, float* q, float* r, float* p);
     bool debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, float* node_L, size_t nodes);
 
     Camera camera;

@@ -1,0 +1,234 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact for everything the render path computes: hit records, per-node light
+terms, film sums, tonemapped pixels.  Run on the GPU box: pytest -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def make(pkg, scenes, name, w, h, **kw):
+    return pkg.create_raytracer_from_arrays(scenes(name), pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, **kw)
+
+
+def test_device_arithmetic_is_ieee(pkg, scenes, oracle):
+    """a/b and sqrt on the device are correctly rounded (what numpy float32 gives), denormals
+    included; a^32 equals the oracle's double-squaring evaluation of powf(x, 32.0)."""
+    rt = make(pkg, scenes, "4boxes", 16, 16)
+    rng = np.random.default_rng(1)
+    a = np.concatenate([rng.uniform(-4, 4, 200000), rng.uniform(0, 1e-38, 1000), [0.0, 1.0, -1.0, 1e30, 3e38, 1e-45]]).astype(np.float32)
+    b = np.concatenate([rng.uniform(-3, 3, 200000), rng.uniform(1e-39, 1e-37, 1000), [1.0, 3.0, 7.0, 1e-30, 3.0, 2.0]]).astype(np.float32)
+    q, r, p = rt.debug_numerics(a, b)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(bits(q), bits(a / b))
+        ok = a >= 0
+        assert np.array_equal(bits(r[ok]), bits(np.sqrt(a[ok])))
+        expect = (a.astype(np.float64) ** 32).astype(np.float32)
+    assert np.array_equal(bits(p), bits(expect))
+    for i in range(0, 2000, 40):
+        assert bits(np.float32(oracle.pow32(a[i])))[()] == bits(p[i:i + 1])[0]
+
+
+@pytest.mark.parametrize("name", ["4boxes", "ico2", "thai2"])
+def test_sample_table_matches_oracle(pkg, scenes, oracle, name):
+    rt = make(pkg, scenes, name, 32, 32, seed=5)
+    orc = oracle.Oracle(scenes(name), 32, 32, seed=5)
+    assert np.array_equal(bits(rt.sample_table()), bits(orc.sample_table()))
+
+
+@pytest.mark.parametrize("name,n", [("4boxes", 60000), ("ico2", 60000), ("thai2", 12000)])
+def test_closest_hit_matches_brute_force_oracle(pkg, scenes, oracle, name, n):
+    """Intersector seam: BVH traversal == NoAccelerationIntersector (true closest hit), bit-exact
+    t/u/v and identical triangle, on primary rays, rays from surface points and random rays."""
+    w, h = 320, 200
+    rt = make(pkg, scenes, name, w, h, seed=3)
+    orc = oracle.Oracle(scenes(name), w, h, seed=3, flags=oracle.FLAG_BRUTE_FORCE)
+    rng = np.random.default_rng(11)
+    prim_rays = np.stack([orc.primary_ray(int(p), 0) for p in rng.integers(0, w * h, n // 3)])
+    tuv, prim = orc.intersect(prim_rays, brute=True)
+    hitm = prim != 0xFFFFFFFF
+    pts = prim_rays[hitm, :3] + tuv[hitm, :1] * prim_rays[hitm, 3:]
+    dirs = rng.normal(size=(pts.shape[0], 3)).astype(np.float32)
+    sec = np.concatenate([pts + 1e-5 * dirs, dirs], axis=1).astype(np.float32)
+    sc = scenes(name)
+    lo, hi = sc["tri_verts"].reshape(-1, 3).min(0), sc["tri_verts"].reshape(-1, 3).max(0)
+    org = rng.uniform(lo - 2, hi + 2, (n // 3, 3)); tgt = rng.uniform(lo, hi, (n // 3, 3))
+    rnd = np.concatenate([org, tgt - org], axis=1).astype(np.float32)
+    rays = np.concatenate([prim_rays, sec, rnd]).astype(np.float32)
+    o_tuv, o_prim = orc.intersect(rays, brute=True)
+    g_tuv, g_prim = rt.intersect_rays(rays)
+    assert (o_prim != 0xFFFFFFFF).sum() > n // 10
+    assert np.array_equal(g_prim, o_prim)
+    m = o_prim != 0xFFFFFFFF
+    assert np.array_equal(bits(g_tuv[m]), bits(o_tuv[m]))
+
+
+def test_axis_parallel_and_degenerate_rays(pkg, scenes, oracle):
+    """zero direction components (1/0 = inf in the slab test), rays starting on surfaces."""
+    name = "4boxes"
+    rt = make(pkg, scenes, name, 64, 64)
+    orc = oracle.Oracle(scenes(name), 64, 64, flags=oracle.FLAG_BRUTE_FORCE)
+    rays = []
+    for ax in range(3):
+        for sgn in (-1.0, 1.0):
+            for k in range(200):
+                o = np.array([2.0, 0.2, 2.0], np.float32) + np.float32(k * 0.013)
+                d = np.zeros(3, np.float32); d[ax] = sgn
+                o[ax] -= sgn * 9.0
+                rays.append(np.concatenate([o, d]))
+    rays.append(np.array([0, 0, 0, 0, 0, 0], np.float32))        # null direction: never hits
+    rays.append(np.array([1.0, 1.0, 1.0, 0, -1, 0], np.float32))  # starts on a box face
+    rays = np.stack(rays).astype(np.float32)
+    o_tuv, o_prim = orc.intersect(rays, brute=True)
+    g_tuv, g_prim = rt.intersect_rays(rays)
+    assert np.array_equal(g_prim, o_prim)
+    m = o_prim != 0xFFFFFFFF
+    assert m.sum() > 100
+    assert np.array_equal(bits(g_tuv[m]), bits(o_tuv[m]))
+
+
+@pytest.mark.parametrize("name", ["4boxes", "ico2", "thai2"])
+def test_per_node_light_terms_match_oracle(pkg, scenes, oracle, name):
+    """stage-level parity: shade() term of every node of the radiance tree + the sample colour."""
+    w, h = 96, 96
+    rt = make(pkg, scenes, name, w, h, seed=9)
+    orc = oracle.Oracle(scenes(name), w, h, seed=9, flags=oracle.FLAG_BRUTE_FORCE)
+    rng = np.random.default_rng(2)
+    checked = 0
+    for pixel in rng.integers(0, w * h, 150):
+        oc, ol, oh = orc.sample_debug(int(pixel), 3)
+        gc, gl = rt.debug_sample(int(pixel), 3)
+        assert np.array_equal(bits(gl), bits(ol)), (pixel, gl, ol)
+        assert np.array_equal(bits(gc), bits(oc)), (pixel, gc, oc)
+        checked += int(oh[0])
+    assert checked > 10
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("4boxes", 64, 64, 4), ("ico2", 64, 64, 4), ("thai2", 64, 64, 4), ("ico2", 96, 40, 3)])
+def test_film_bit_exact_vs_brute_force_oracle(pkg, scenes, oracle, name, w, h, spp):
+    """whole path: seeded render, film sums / squares / counts and packed pixels identical."""
+    rt = make(pkg, scenes, name, w, h, seed=1)
+    orc = oracle.Oracle(scenes(name), w, h, seed=1, flags=oracle.FLAG_BRUTE_FORCE)
+    counts = rt.render(spp)
+    oc = orc.render(spp, nthreads=8)
+    assert (counts.primary, counts.bounce, counts.shadow, counts.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+    gs, gq, gn = rt.film.pixel_datas()
+    os_, oq, on = orc.film()
+    assert np.array_equal(gn, on)
+    assert np.array_equal(bits(gs), bits(os_))
+    assert np.array_equal(bits(gq), bits(oq))
+    assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
+    assert np.array_equal(bits(rt.film.get_pixels()), bits(orc.get_pixels()))
+
+
+def test_trace_frame_additive_matches_oracle(pkg, scenes, oracle):
+    """the reference's own entry: 50 rows x 1 sample per call, row cursor wraps, unsampled rows
+    read back white (NaN -> 255), film.clear() restarts the accumulation but not the cursor."""
+    name, w, h = "ico2", 64, 120
+    rt = make(pkg, scenes, name, w, h, seed=4)
+    orc = oracle.Oracle(scenes(name), w, h, seed=4, flags=oracle.FLAG_BRUTE_FORCE)
+    for call in range(4):
+        assert rt.trace_frame_additive() == orc.trace_frame_additive() == 50 * w
+        assert rt.current_row == orc.current_row
+        g = rt.get_tonemapped_pixels(); o = orc.get_tonemapped_pixels()
+        assert np.array_equal(g, o)
+        if call == 0:
+            assert np.all(g[50 * w:] == 0xFFFFFFFF)          # rows not sampled yet: white
+    gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+    assert np.array_equal(gn, on) and gn.max() == 2 and gn.min() == 1
+    assert np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+    rt.film.clear(); orc.film_clear()
+    assert rt.trace_frame_additive() == orc.trace_frame_additive()
+    assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
+
+
+def test_small_height_row_wrap(pkg, scenes, oracle):
+    """height < 50: one call wraps the row cursor and samples rows more than once."""
+    name, w, h = "4boxes", 40, 16
+    rt = make(pkg, scenes, name, w, h, seed=2)
+    orc = oracle.Oracle(scenes(name), w, h, seed=2, flags=oracle.FLAG_BRUTE_FORCE)
+    assert rt.trace_frame_additive() == orc.trace_frame_additive()
+    gs, _, gn = rt.film.pixel_datas(); os_, _, on = orc.film()
+    assert np.array_equal(gn, on) and gn.max() == 4
+    assert np.array_equal(bits(gs), bits(os_))
+
+
+def test_camera_moves_match_oracle(pkg, scenes, oracle):
+    name, w, h = "ico2", 48, 48
+    rt = make(pkg, scenes, name, w, h, seed=6)
+    orc = oracle.Oracle(scenes(name), w, h, seed=6, flags=oracle.FLAG_BRUTE_FORCE)
+    rt.camera.move_rel(0.1, 0.0, 0.0); orc.camera_move_rel(0.1, 0.0, 0.0)
+    rt.camera.add_y_angle(0.01); orc.camera_add_y_angle(0.01)
+    rt.camera.add_x_angle(-0.02); orc.camera_add_x_angle(-0.02)
+    rt.camera.move_rel(0.0, -0.1, 0.1); orc.camera_move_rel(0.0, -0.1, 0.1)
+    for a, b in zip(rt.camera.matrices(), orc.camera_matrices()):
+        assert np.array_equal(bits(a), bits(b))
+    rt.film.clear(); orc.film_clear()
+    rt.render(2); orc.render(2, nthreads=8)
+    assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0]))
+
+
+def test_fix_row_index_flag(pkg, scenes, oracle):
+    name, w, h = "ico2", 80, 48
+    rt = make(pkg, scenes, name, w, h, seed=8, flags=pkg.FLAG_FIX_ROW_INDEX)
+    orc = oracle.Oracle(scenes(name), w, h, seed=8, flags=oracle.FLAG_BRUTE_FORCE | oracle.FLAG_FIX_ROW_INDEX)
+    rt.render(2); orc.render(2, nthreads=8)
+    assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0]))
+
+
+def test_textured_scene_matches_oracle(pkg, scenes, oracle):
+    """ico3_tex: Diffuse::TextureId -> nearest texel at the hit's barycentric (u, v)."""
+    name, w, h = "ico3_tex", 64, 64
+    rt = make(pkg, scenes, name, w, h, seed=1)
+    orc = oracle.Oracle(scenes(name), w, h, seed=1, flags=oracle.FLAG_BRUTE_FORCE)
+    rt.render(3); orc.render(3, nthreads=8)
+    assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0]))
+
+
+@pytest.mark.parametrize("rec,spread", [(0, 1), (1, 2), (3, 1), (2, 2)])
+def test_other_recursion_settings(pkg, scenes, oracle, rec, spread):
+    name, w, h = "ico2", 40, 40
+    rt = make(pkg, scenes, name, w, h, seed=1, recursions=rec, spread=spread)
+    orc = oracle.Oracle(scenes(name), w, h, seed=1, recursions=rec, spread=spread, flags=oracle.FLAG_BRUTE_FORCE)
+    c = rt.render(2); oc = orc.render(2, nthreads=8)
+    assert (c.bounce, c.shadow) == (oc["bounce"], oc["shadow"])
+    assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0]))
+
+
+def test_shadow_predicate(pkg, scenes, oracle):
+    """occluded_rays == `closest hit has 0.01 < t < 1.0` (mod.rs:226-229) on the oracle's closest hit."""
+    name = "thai2"
+    rt = make(pkg, scenes, name, 64, 64)
+    orc = oracle.Oracle(scenes(name), 64, 64, flags=oracle.FLAG_BRUTE_FORCE)
+    sc = scenes(name)
+    rng = np.random.default_rng(5)
+    lo, hi = sc["tri_verts"].reshape(-1, 3).min(0), sc["tri_verts"].reshape(-1, 3).max(0)
+    org = rng.uniform(lo, hi, (6000, 3)); light = sc["lights"][0, :3]
+    rays = np.concatenate([org, light - org], axis=1).astype(np.float32)
+    tuv, prim = orc.intersect(rays, brute=True)
+    expect = (prim != 0xFFFFFFFF) & (tuv[:, 0] > np.float32(0.01)) & (tuv[:, 0] < np.float32(1.0))
+    got = rt.occluded_rays(rays)
+    assert expect.sum() > 100 and (~expect).sum() > 100
+    assert np.array_equal(got.astype(bool), expect)
+
+
+def test_stripes_partition_the_frame(pkg, scenes, oracle):
+    """N stripe handles (the per-GPU decomposition) produce exactly the single-handle film."""
+    name, w, h, spp = "ico2", 64, 50, 2
+    full = make(pkg, scenes, name, w, h, seed=3)
+    full.render(spp)
+    fs, _, fn = full.film.pixel_datas()
+    acc = np.zeros_like(fs); cnt = np.zeros_like(fn)
+    for rank in range(3):
+        part = make(pkg, scenes, name, w, h, seed=3, stripe_rows=4, stripe_rank=rank, stripe_world=3)
+        part.render(spp)
+        ps, _, pn = part.film.pixel_datas()
+        rows = part.owned_rows()
+        assert np.all((rows // 4) % 3 == rank)
+        acc += ps; cnt += pn
+    assert np.array_equal(cnt, fn)
+    assert np.array_equal(bits(acc), bits(fs))
