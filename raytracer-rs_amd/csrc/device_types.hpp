@@ -14,6 +14,8 @@ constexpr uint32_t kMaxLevels = kMaxRecursions + 1;
 //   q2 = radiance ray: (pixel, sample#, -, -) as bits;  shadow ray: (L.r, L.g, L.b, -)
 // meta: bit 0 kind (0 radiance, 1 shadow) | level << 4 | node << 8 | light << 24
 constexpr uint32_t kRayRecordBytes = 48;
+constexpr uint32_t kShards = 64;            // copies of every contended device word (work cursors, counters)
+constexpr uint32_t kMaxRounds = kMaxRecursions + 2;
 
 struct DMaterial { float r, g, b; uint32_t kind_tex; };       // kind_tex: bit 31 = texture, low bits = texture id
 struct DLight { float px, py, pz, cr, cg, cb; };
@@ -54,7 +56,13 @@ struct DPass {
     uint32_t nodes_per_sample;
     uint32_t level_first[kMaxLevels + 1];
     uint32_t use_explicit, explicit_pixel, explicit_sampleno;
-    uint32_t out_capacity;    // records
+    uint32_t chunk;           // primary samples per chunk
+    uint32_t nchunks;         // ceil(nsamples / chunk)
+    uint32_t region;          // queue records reserved per chunk = chunk * worst-case records per sample
+    uint32_t stack_depth;     // traversal stack rows in LDS (BVH max depth + 1)
+    uint32_t leaf_threshold;  // trace kernel: run the triangle code once this many lanes wait at a leaf
+    uint32_t pull_mode;       // work distribution experiment switch (1 = default)
+    uint32_t list_cap;        // shade kernel: LDS hit-list entries per wave (max radiance rays per chunk)
 };
 
 struct DCounters {            // one set per render call, zeroed at its start

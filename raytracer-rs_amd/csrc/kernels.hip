@@ -1,173 +1,74 @@
 // kernels.hip — gfx950 (CDNA4, wave64) kernels of the render path.
 //
-// Wavefront structure of one pass over N primary samples:
-//   round 0      : ray-gen + closest hit of the primary rays                       (mod.rs:93-98)
-//   round r >= 1 : closest hit of level-r reflection rays and of the shadow rays
-//                  emitted by level r-1                                             (mod.rs:158, 226)
-//   every round  : on a radiance hit, shade() set-up — normal, Phong terms, shadow ray
-//                  (mod.rs:198-257) — and the level r+1 reflection rays (mod.rs:178-196) are
-//                  appended to the next queue with a wave64 ballot + prefix-popcount and ONE
-//                  atomic per wave; a finished unblocked shadow ray stores its light term.
-//   resolve      : per pixel, combine the per-node light terms in the reference's own
-//                  summation order (mod.rs:154-175) and add the samples to the film in sample
-//                  order (film.rs:20-24).
+// Wavefront structure of one pass over N primary samples.  The samples are cut into
+// chunks of ps.chunk; a chunk keeps its identity through every round: its rays of round r live in
+// region `chunk` of that round's queue (ps.region records, the worst case) — radiance rays packed
+// from the front, shadow rays packed from the back — with (n_radiance, n_shadow) in counts[chunk].
 //
-// Numerics: this file is compiled with -ffp-contract=off; everything that decides a result
-// (Moller-Trumbore, shading, camera, film, tonemap) is written in the reference's operation
-// order with IEEE f32 +,-,*,/ and sqrt, so results are bit-comparable with unfused CPU code.
-// Only the BVH box tests are free-form: boxes are padded (bvh.cpp) and the test is conservative.
+//   trace  round r : closest hit of every ray of the round (round 0: ray-gen from the sample index,
+//                    mod.rs:93-98).  Persistent waves; a lane that finishes its ray is refilled from
+//                    the wave's current chunk (wave64 ballot + prefix popcount, no atomics; one atomic
+//                    per CHUNK to pull the next one), so lanes stay busy although ray lengths differ.
+//                    A radiance ray stores its hit record; a finished unblocked shadow ray stores its
+//                    light term (mod.rs:232-256).
+//   shade  round r : one wave per chunk.  Hits are compacted into an LDS index list (ballot +
+//                    prefix popcount), then shade() set-up — normal, Phong terms, shadow ray
+//                    (mod.rs:198-257) — and the level r+1 reflection rays (mod.rs:178-196) are
+//                    appended to the chunk's region of the next queue with wave-local counters.
+//   resolve        : per pixel, combine the per-node light terms in the reference's own summation
+//                    order (mod.rs:154-175) and add the samples to the film in sample order
+//                    (film.rs:20-24).
+//
+// Numerics: compiled with -ffp-contract=off; everything that decides a result (Moller-Trumbore,
+// shading, camera, film, tonemap) is IEEE f32 in the reference's operation order.  Only the BVH box
+// tests are free-form: boxes are padded (bvh.cpp) and the test is conservative.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "device_math.hpp"
 #include "device_types.hpp"
 #include "kernels.hpp"
+#include "traverse.hpp"
 
 namespace mi355rt {
 
 constexpr int kBlock = 256;
-constexpr int kStackDepth = 32;          // >= kBvhMaxDepth + 1
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr uint32_t kMiss = 0xFFFFFFFFu;
 
-struct f3 { float x, y, z; };
-// IEEE correctly rounded f32 divide / sqrt: plain `/` and sqrtf under
-// -fhip-fp32-correctly-rounded-divide-sqrt (HIP's __fdiv_rn/__fsqrt_rn are NOT: __fsqrt_rn is the
-// native approximation).  tests/test_gpu_numerics.py checks both against IEEE on the device.
-__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
-__device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }
-__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ f3 vscale(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }    // Vec3 * f32
-__device__ __forceinline__ f3 sscale(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }    // f32 * Vec3
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vecmath.rs:74-76
-__device__ __forceinline__ f3 cross3(f3 a, f3 b)                                                  // vecmath.rs:79-85
+// One device word sustains only ~88 atomics/us on this chip: the statistics counters that every wave
+// flushes into exist in kShards copies (the host adds them up), and the work cursor is touched
+// sparingly (pull_chunk).
+__device__ __forceinline__ uint32_t global_wave_id() { return blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); }
+
+// Pull the next chunk for this wave (wave-uniform).  mode 0: one atomic on the shared cursor per
+// pull (dynamic balancing; the cursor word sustains ~88 pulls/us, far above the demand of a few
+// thousand chunks per millisecond).  mode 2: static striding, no atomics (wave w takes chunks
+// w, w + nwaves, ...).  Measured on thai2 1080p: dynamic wins for passes >= 16M samples, static for
+// smaller ones (profiles/r01_notes.md).  A relaxed agent-scope load of the cursor in front of the
+// atomic (to skip the end-of-kernel storm) made the kernel 2.5x slower and was dropped.
+__device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, bool& first, uint32_t& chunk)
 {
-    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-__device__ __forceinline__ f3 normalized3(f3 a)                                                   // vecmath.rs:23-26
-{
-    float len = sqrt_rn(a.x * a.x + a.y * a.y + a.z * a.z);
-    return mk3(div_rn(a.x, len), div_rn(a.y, len), div_rn(a.z, len));
-}
-
-// counter RNG (replaces the reference's OS-entropy StdRng): pcg4d, Jarzynski & Olano 2020
-__device__ __forceinline__ void pcg4d(uint32_t& x, uint32_t& y, uint32_t& z, uint32_t& w)
-{
-    x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u;
-    z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
-    x += y * w; y += z * x; z += x * y; w += y * z;
-    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
-    x += y * w; y += z * x; z += x * y; w += y * z;
-}
-__device__ __forceinline__ float u01(uint32_t bits) { return (float)(bits >> 9) * (1.0f / 8388608.0f); }
-
-// x.powf(32.0), mod.rs:255: five squarings in f64, rounded once
-__device__ __forceinline__ float pow32(float x)
-{
-    double d = (double)x;
-    d = d * d; d = d * d; d = d * d; d = d * d; d = d * d;
-    return (float)d;
-}
-
-struct Hit {
-    float t, u, v;
-    uint32_t prim;      // 0xFFFFFFFF = miss
-    int occ;            // shadow rays: 0 nothing in [0,1), 1 blocked (closest hit in (0.01,1)), 2 a hit at t <= 0.01
-};
-
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-
-// Closest-hit traversal of the BVH2.  Radiance rays: true closest hit (lowest t, ties to the
-// lowest triangle index == first in the reference's list order, no_acceleration_intersector.rs).
-// Shadow rays: only the predicate of mod.rs:226-229 is needed — "the CLOSEST hit has
-// 0.01 < t < 1.0" — so the search interval shrinks to [0, 0.01] after the first hit inside
-// (0.01, 1) and stops at the first hit with t <= 0.01.
-template <bool COUNT>
-__device__ __forceinline__ void traverse(const DScene& sc, f3 o, f3 d, bool shadow, int* stack, Hit& r,
-                                          uint32_t& n_nodes, uint32_t& n_tris)
-{
-    const float4* __restrict__ nodes = (const float4*)sc.nodes;
-    const float4* __restrict__ tris = (const float4*)sc.tris;
-    const float idx = __builtin_amdgcn_rcpf(d.x), idy = __builtin_amdgcn_rcpf(d.y), idz = __builtin_amdgcn_rcpf(d.z);
-    float tlimit = shadow ? 0x1.fffffep-1f : __builtin_inff();     // shadow: t < 1.0
-    r.t = __builtin_inff(); r.u = 0.0f; r.v = 0.0f; r.prim = 0xFFFFFFFFu; r.occ = 0;
-    int node = sc.root;
-    int sp = 0;
-    for (;;) {
-        if (node >= 0) {
-            if (COUNT) ++n_nodes;
-            const float4 q0 = nodes[4 * node], q1 = nodes[4 * node + 1], q2 = nodes[4 * node + 2];
-            const float4 q3 = nodes[4 * node + 3];
-            float a1 = (q0.x - o.x) * idx, a2 = (q0.y - o.x) * idx;
-            float b1 = (q0.z - o.y) * idy, b2 = (q0.w - o.y) * idy;
-            float c1 = (q2.x - o.z) * idz, c2 = (q2.y - o.z) * idz;
-            float tn0 = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
-            float tf0 = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), tlimit));
-            a1 = (q1.x - o.x) * idx; a2 = (q1.y - o.x) * idx;
-            b1 = (q1.z - o.y) * idy; b2 = (q1.w - o.y) * idy;
-            c1 = (q2.z - o.z) * idz; c2 = (q2.w - o.z) * idz;
-            float tn1 = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
-            float tf1 = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), tlimit));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            const int c0i = __float_as_int(q3.x), c1i = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool sw = tn1 < tn0;
-                stack[sp * kBlock] = sw ? c0i : c1i;
-                ++sp;
-                node = sw ? c1i : c0i;
-                continue;
-            }
-            if (h0) { node = c0i; continue; }
-            if (h1) { node = c1i; continue; }
-        } else {
-            const uint32_t code = ~(uint32_t)node;
-            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-            bool done = false;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                if (COUNT) ++n_tris;
-                const float4 t0 = tris[3 * (first + i)], t1 = tris[3 * (first + i) + 1], t2 = tris[3 * (first + i) + 2];
-                // Moller-Trumbore "late out", intersect.rs:62-98, same operation order
-                const f3 v0 = mk3(t0.x, t0.y, t0.z), v0v1 = mk3(t1.x, t1.y, t1.z), v0v2 = mk3(t2.x, t2.y, t2.z);
-                const f3 pvec = cross3(d, v0v2);
-                const float det = dot3(v0v1, pvec);
-                if (fabsf(det) < 1.1920929e-7f) continue;
-                const float inv_det = div_rn(1.0f, det);
-                const f3 tvec = sub3(o, v0);
-                const float u = dot3(tvec, pvec) * inv_det;
-                const f3 qvec = cross3(tvec, v0v1);
-                const float v = dot3(d, qvec) * inv_det;
-                const float t = dot3(v0v2, qvec) * inv_det;
-                if (u < 0.0f || u > 1.0f) continue;
-                if (v < 0.0f || u + v > 1.0f) continue;
-                if (t < 0.0f) continue;
-                const uint32_t prim = __float_as_uint(t0.w);
-                if (!shadow) {
-                    if (r.prim == 0xFFFFFFFFu || t < r.t || (t == r.t && prim < r.prim)) {
-                        r.t = t; r.u = u; r.v = v; r.prim = prim; tlimit = t;
-                    }
-                } else if (t <= tlimit) {
-                    if (t > 0.01f) { r.occ = 1; tlimit = 0.01f; }
-                    else { r.occ = 2; done = true; break; }
-                }
-            }
-            if (done) break;
-        }
-        if (sp == 0) break;
-        --sp;
-        node = stack[sp * kBlock];
+    if (mode == 2u) {
+        if (first) { first = false; chunk = global_wave_id(); }
+        else chunk += gridDim.x * kWavesPerBlock;
+        return chunk < nchunks;
     }
+    uint32_t v = 0u;
+    if (lane_id() == 0) v = atomicAdd(cursor, 1u);
+    chunk = bcast_first(v);
+    return chunk < nchunks;
 }
 
 // wave64 compaction: every lane of the wave calls this; lanes with want == true get consecutive
-// indices of the output queue; one atomic per wave.
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter, uint32_t& n_out)
+// indices after the wave's running count `n` (ballot + prefix popcount, no atomic: the wave owns the
+// region it appends to).
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t& n, uint32_t& n_new)
 {
     const unsigned long long mask = __ballot(want);
-    n_out = (uint32_t)__popcll(mask);
-    if (mask == 0ull) return 0u;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0u;
-    if (lane_id() == leader) base = atomicAdd(counter, n_out);
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+    n_new = (uint32_t)__popcll(mask);
+    const uint32_t idx = n + (uint32_t)__popcll(mask & lanemask_lt());
+    n += n_new;
+    return idx;
 }
 
 __device__ __forceinline__ f3 fetch_texel(const DScene& sc, uint32_t tex, float u, float v)     // texture.rs:21-27
@@ -185,162 +86,251 @@ __device__ __forceinline__ f3 fetch_texel(const DScene& sc, uint32_t tex, float 
     return mk3(p[0], p[1], p[2]);
 }
 
-template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(kBlock) void trace_round_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
-                                                            const float4* __restrict__ in_q, const uint32_t* __restrict__ in_count,
-                                                            float4* __restrict__ out_q, uint32_t* out_count, uint32_t* cursor,
-                                                            float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
-                                                            DCounters* counters)
+// pixel -> primary ray, mod.rs:93-96 + camera.rs:80-90.  gi = index of the primary sample in the pass.
+__device__ __forceinline__ void primary_sample(const DCamera& cam, const DPass& ps, const uint32_t* __restrict__ film_n, uint32_t gi,
+                                               uint32_t& pixel, uint32_t& sampleno, f3& o, f3& d)
 {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    if (ps.use_explicit) { pixel = ps.explicit_pixel; sampleno = ps.explicit_sampleno; }
+    else {
+        const uint32_t s = gi / ps.npix, p = gi - s * ps.npix;
+        pixel = ps.rows[ps.row0 + p / cam.width] * cam.width + p % cam.width;
+        sampleno = film_n[pixel] + s;
+    }
+    uint32_t h0 = pixel, h1 = sampleno, h2 = 0u, h3 = ps.seed;
+    pcg4d(h0, h1, h2, h3);
+    const uint32_t cu = pixel % cam.width;
+    const uint32_t cv = (ps.flags & 1u) ? pixel / cam.width : pixel / cam.height;   // reference: idx / height
+    const float dir_x = -cam.max_x + 2.0f * cam.max_x * div_rn((float)cu + u01(h0), (float)cam.width);
+    const float dir_y = -cam.max_y + 2.0f * cam.max_y * div_rn((float)cv + u01(h1), (float)cam.height);
+    const float vx = dir_x, vy = -dir_y, vz = 1.0f, vw = 1.0f;
+    d.x = vx * cam.rot[0] + vy * cam.rot[4] + vz * cam.rot[8] + vw * cam.rot[12];
+    d.y = vx * cam.rot[1] + vy * cam.rot[5] + vz * cam.rot[9] + vw * cam.rot[13];
+    d.z = vx * cam.rot[2] + vy * cam.rot[6] + vz * cam.rot[10] + vw * cam.rot[14];
+    o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+}
+
+// record index of ray i of a chunk: radiance rays from the front, shadow rays from the back
+__device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, uint32_t i, uint32_t n_rad)
+{
+    const size_t base = (size_t)chunk * ps.region;
+    return i < n_rad ? base + i : base + (ps.region - 1u - (i - n_rad));
+}
+
+// ---- trace: closest hit of every ray of a round --------------------------------------------------
+template <bool PRIMARY, bool COUNT>
+__global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, DPass ps,
+                                                      const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                                      float4* __restrict__ hits, uint32_t* cursor,
+                                                      float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
+                                                      DCounters* counters)
+{
+    extern __shared__ int s_stack[];                 // ps.stack_depth rows of kBlock ints
     int* stack = &s_stack[threadIdx.x];
-    const uint32_t total = PRIMARY ? ps.nsamples : *in_count;
-    const int lane = lane_id();
-    uint32_t acc_nodes = 0, acc_tris = 0, acc_bounce = 0, acc_shadow = 0, acc_phits = 0;
+    uint32_t acc_nodes = 0, acc_tris = 0;
+
+    // wave-uniform work state: the chunk being handed out
+    uint32_t w_chunk = 0u, w_next = 0u, w_nrad = 0u, w_ntot = 0u;
+    bool exhausted = false;
+    bool w_first = true;
+    // lane state
+    bool busy = false;
+    RayState rs;
+    size_t rec = 0;                                  // radiance: hit-record index; shadow: queue record index
+    ray_init(rs, mk3(0, 0, 0), mk3(0, 0, 1), false, sc.root);
 
     for (;;) {
-        uint32_t base = 0u;
-        if (lane == 0) base = atomicAdd(cursor, 64u);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= total) break;
-        const uint32_t i = base + (uint32_t)lane;
-        const bool active = i < total;
-
-        f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
-        uint32_t slot = 0u, meta = 0u, pixel = 0u, sampleno = 0u;
-        f3 L = mk3(0.0f, 0.0f, 0.0f);
-        if (active) {
-            if (PRIMARY) {
-                // pixel -> ray, mod.rs:93-96 + camera.rs:80-90
-                const uint32_t s = i / ps.npix, p = i - s * ps.npix;
-                if (ps.use_explicit) pixel = ps.explicit_pixel;
-                else pixel = ps.rows[ps.row0 + p / cam.width] * cam.width + p % cam.width;
-                sampleno = ps.use_explicit ? ps.explicit_sampleno : film_n[pixel] + s;
-                slot = i;
-                uint32_t h0 = pixel, h1 = sampleno, h2 = 0u, h3 = ps.seed;
-                pcg4d(h0, h1, h2, h3);
-                const uint32_t cu = pixel % cam.width;
-                const uint32_t cv = (ps.flags & 1u) ? pixel / cam.width : pixel / cam.height;   // reference: idx / height
-                const float dir_x = -cam.max_x + 2.0f * cam.max_x * div_rn((float)cu + u01(h0), (float)cam.width);
-                const float dir_y = -cam.max_y + 2.0f * cam.max_y * div_rn((float)cv + u01(h1), (float)cam.height);
-                const float vx = dir_x, vy = -dir_y, vz = 1.0f, vw = 1.0f;
-                d.x = vx * cam.rot[0] + vy * cam.rot[4] + vz * cam.rot[8] + vw * cam.rot[12];
-                d.y = vx * cam.rot[1] + vy * cam.rot[5] + vz * cam.rot[9] + vw * cam.rot[13];
-                d.z = vx * cam.rot[2] + vy * cam.rot[6] + vz * cam.rot[10] + vw * cam.rot[14];
-                o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
-                meta = 0u;
-            } else {
-                const float4 r0 = in_q[3 * (size_t)i], r1 = in_q[3 * (size_t)i + 1], r2 = in_q[3 * (size_t)i + 2];
-                o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
-                slot = __float_as_uint(r1.z); meta = __float_as_uint(r1.w);
-                if (meta & 1u) L = mk3(r2.x, r2.y, r2.z);
-                else { pixel = __float_as_uint(r2.x); sampleno = __float_as_uint(r2.y); }
+        // ---- refill idle lanes from the current chunk (pull a new chunk when it runs dry)
+        unsigned long long idle = __ballot(!busy);
+        while (idle != 0ull && !exhausted) {
+            if (w_next >= w_ntot) {
+                uint32_t c = 0u;
+                c = w_chunk;
+                if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, w_first, c)) { exhausted = true; break; }
+                w_chunk = c; w_next = 0u;
+                if (PRIMARY) { w_nrad = min(ps.chunk, ps.nsamples - c * ps.chunk); w_ntot = w_nrad; }
+                else { const uint2 n = in_counts[c]; w_nrad = n.x; w_ntot = n.x + n.y; }
+                continue;
             }
+            const uint32_t avail = w_ntot - w_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
+            if (!busy && rank < avail) {
+                const uint32_t i = w_next + rank;
+                f3 o, d;
+                bool shadow = false;
+                if (PRIMARY) {
+                    uint32_t pixel, sampleno;
+                    primary_sample(cam, ps, film_n, w_chunk * ps.chunk + i, pixel, sampleno, o, d);
+                    rec = (size_t)w_chunk * ps.region + i;
+                } else {
+                    const size_t r = record_index(ps, w_chunk, i, w_nrad);
+                    const float4 r0 = in_q[3 * r], r1 = in_q[3 * r + 1];
+                    o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+                    shadow = i >= w_nrad;
+                    rec = r;
+                }
+                ray_init(rs, o, d, shadow, sc.root);
+                busy = true;
+            }
+            w_next += min((uint32_t)__popcll(idle), avail);
+            idle = __ballot(!busy);
         }
-        const bool shadow = (meta & 1u) != 0u;
-        Hit hit;
-        hit.prim = 0xFFFFFFFFu; hit.occ = 0; hit.t = 0.0f; hit.u = 0.0f; hit.v = 0.0f;
-        if (active) traverse<COUNT>(sc, o, d, shadow, stack, hit, acc_nodes, acc_tris);
+        if (__ballot(busy) == 0ull) break;
 
-        const uint32_t node = (meta >> 8) & 0xFFFFu;
-        if (active && shadow) {
-            if (hit.occ != 1) {                                    // not blocked, mod.rs:232
-                const uint32_t light = meta >> 24;
+        // ---- while-while scheduling: inner-node steps run for the lanes at inner nodes; lanes that
+        // reached a leaf wait until enough of them are there (or nobody is left at an inner node),
+        // so that the expensive triangle code always runs with a well-filled wave.
+        const unsigned long long m_inner = __ballot(busy && rs.node >= 0);
+        bool fin = false;
+        if (m_inner != 0ull) {
+            if (busy && rs.node >= 0) fin = inner_step<COUNT>(sc, rs, stack, kBlock, acc_nodes);
+        }
+        const unsigned long long m_leaf = __ballot(busy && !fin && rs.node < 0);
+        if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(busy && !fin && rs.node >= 0) == 0ull)) {
+            if (busy && !fin && rs.node < 0) fin = leaf_step<COUNT>(sc, rs, stack, kBlock, acc_tris);
+        }
+        if (fin) {
+            busy = false;
+            if (!rs.shadow) {
+                hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
+            } else if (rs.occ != 1) {                                  // not blocked, mod.rs:232
+                const float4 r1 = in_q[3 * rec + 1], r2 = in_q[3 * rec + 2];
+                const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
+                const uint32_t node = (meta >> 8) & 0xFFFFu, light = meta >> 24;
                 float* dst = slot_L + 3ull * (((size_t)slot * ps.nodes_per_sample + node) * sc.nlights + light);
-                dst[0] = L.x; dst[1] = L.y; dst[2] = L.z;
-            }
-        }
-        const bool rad_hit = active && !shadow && hit.prim != 0xFFFFFFFFu;
-        if (PRIMARY) acc_phits += rad_hit ? 1u : 0u;
-        if (__ballot(rad_hit) == 0ull) continue;
-
-        // ---- shade() set-up, mod.rs:207-257 (every lane walks the loops; only hit lanes emit)
-        f3 hp = mk3(0, 0, 0), n = mk3(0, 0, 1);
-        uint32_t geom = 0u;
-        if (rad_hit) {
-            hp = add3(o, sscale(hit.t, d));                                          // mod.rs:212
-            const float4 nn = ((const float4*)sc.normals)[hit.prim];                 // calc_normal, mod.rs:198-205 (precomputed)
-            n = mk3(nn.x, nn.y, nn.z);
-            geom = __float_as_uint(nn.w);
-        }
-        for (uint32_t li = 0; li < sc.nlights; ++li) {
-            bool want = false;
-            f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 1), c = mk3(0, 0, 0);
-            if (rad_hit) {
-                const DLight lt = sc.lights[li];
-                const f3 l = sub3(mk3(lt.px, lt.py, lt.pz), hp);                       // mod.rs:215
-                const f3 ln = normalized3(l);
-                const float ndl = dot3(n, ln);                                         // mod.rs:216
-                if (!(ndl < 0.0f)) {                                                   // mod.rs:218
-                    want = true;
-                    so = add3(hp, vscale(l, 0.01f)); sd = l;                           // mod.rs:224-225
-                    const DMaterial m = sc.materials[geom];
-                    f3 diffuse = mk3(m.r, m.g, m.b);
-                    if (m.kind_tex & 0x80000000u) diffuse = fetch_texel(sc, m.kind_tex & 0x7FFFFFFFu, hit.u, hit.v);
-                    const f3 view = normalized3(d);                                    // mod.rs:251
-                    const f3 refl = sub3(sscale(2.0f * ndl, n), ln);                   // mod.rs:252-253
-                    const float spec = pow32(dot3(view, refl));                        // mod.rs:255, SPECULAR = white
-                    c = mk3((diffuse.x * ndl + spec) * lt.cr, (diffuse.y * ndl + spec) * lt.cg, (diffuse.z * ndl + spec) * lt.cb);
-                }
-            }
-            uint32_t n_out;
-            const uint32_t oi = wave_append(want, out_count, n_out);
-            if (lane == 0) acc_shadow += n_out;
-            if (want) {
-                if (oi < ps.out_capacity) {
-                    out_q[3 * (size_t)oi] = make_float4(so.x, so.y, so.z, sd.x);
-                    out_q[3 * (size_t)oi + 1] = make_float4(sd.y, sd.z, __uint_as_float(slot), __uint_as_float(1u | (level << 4) | (node << 8) | (li << 24)));
-                    out_q[3 * (size_t)oi + 2] = make_float4(c.x, c.y, c.z, 0.0f);
-                } else counters->overflow = 1u;
-            }
-        }
-        // ---- reflection rays, mod.rs:146-158 + 178-196
-        if (level < ps.recursions) {
-            const uint32_t k = ps.spread * (ps.recursions - level);                    // num_sub_rays, mod.rs:150
-            const uint32_t index_in_level = node - ps.level_first[level];
-            for (uint32_t ci = 0; ci < k; ++ci) {
-                const uint32_t child_node = ps.level_first[level + 1] + index_in_level * k + ci;
-                f3 bo = mk3(0, 0, 0), bd = mk3(0, 0, 1);
-                if (rad_hit) {
-                    uint32_t h0 = pixel, h1 = sampleno, h2 = 1u + child_node, h3 = ps.seed;
-                    pcg4d(h0, h1, h2, h3);
-                    uint32_t j = __umulhi(h0, 65535u);                                 // uniform in [0, 65534], sample_generator.rs:32
-                    const float4* __restrict__ table = (const float4*)sc.table;
-                    float4 tv = table[j];
-                    uint32_t guard = 0u;
-                    while (tv.x * n.x + tv.y * n.y + tv.z * n.z <= 0.0f && guard < kNumSamples) {   // mod.rs:187-189
-                        j = (j + 1u) % kSampleMax;                                     // sample_generator.rs:27
-                        tv = table[j];
-                        ++guard;
-                    }
-                    bd = mk3(tv.x, tv.y, tv.z);
-                    bo = add3(hp, sscale(0.00001f, bd));                               // mod.rs:192-193
-                }
-                uint32_t n_out;
-                const uint32_t oi = wave_append(rad_hit, out_count, n_out);
-                if (lane == 0) acc_bounce += n_out;
-                if (rad_hit) {
-                    if (oi < ps.out_capacity) {
-                        out_q[3 * (size_t)oi] = make_float4(bo.x, bo.y, bo.z, bd.x);
-                        out_q[3 * (size_t)oi + 1] = make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8)));
-                        out_q[3 * (size_t)oi + 2] = make_float4(__uint_as_float(pixel), __uint_as_float(sampleno), 0.0f, 0.0f);
-                    } else counters->overflow = 1u;
-                }
+                dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
             }
         }
     }
-    // per-wave counter flush
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { acc_nodes += __shfl_down((int)acc_nodes, off, 64); acc_tris += __shfl_down((int)acc_tris, off, 64); }
-        if (lane == 0) { atomicAdd(&counters->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&counters->tris_tested, (unsigned long long)acc_tris); }
+        DCounters* cs = &counters[global_wave_id() % kShards];
+        if (lane_id() == 0) { atomicAdd(&cs->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&cs->tris_tested, (unsigned long long)acc_tris); }
     }
-    if (PRIMARY) {
-        for (int off = 32; off > 0; off >>= 1) acc_phits += __shfl_down((int)acc_phits, off, 64);
-        if (lane == 0 && acc_phits) atomicAdd(&counters->primary_hits, (unsigned long long)acc_phits);
+}
+
+// ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
+template <bool PRIMARY>
+__global__ __launch_bounds__(kBlock) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
+                                                      const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                                      const float4* __restrict__ hits,
+                                                      float4* __restrict__ out_q, uint2* __restrict__ out_counts,
+                                                      const uint32_t* __restrict__ film_n, DCounters* counters)
+{
+    extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.list_cap hit indices
+    const int lane = lane_id();
+    uint32_t* list = &s_list[(threadIdx.x >> 6) * ps.list_cap];
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+    unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
+
+    for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
+        const uint32_t n_rad = PRIMARY ? min(ps.chunk, ps.nsamples - chunk * ps.chunk) : in_counts[chunk].x;
+        const size_t base = (size_t)chunk * ps.region;
+        // ---- compact the rays that hit something (wave64 ballot + prefix popcount into LDS)
+        uint32_t cnt = 0u;
+        for (uint32_t it = 0; it < n_rad; it += 64u) {
+            const uint32_t i = it + (uint32_t)lane;
+            const bool valid = i < n_rad && __float_as_uint(hits[base + i].w) != kMiss;
+            uint32_t n_new;
+            const uint32_t pos = wave_append(valid, cnt, n_new);
+            if (valid) list[pos] = i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t out_front = 0u, out_back = 0u;
+        for (uint32_t j = 0; j < cnt; j += 64u) {
+            const bool active = j + (uint32_t)lane < cnt;
+            f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), hp = mk3(0, 0, 0), n = mk3(0, 0, 1);
+            uint32_t slot = 0u, node = 0u, pixel = 0u, sampleno = 0u, geom = 0u;
+            float4 h = make_float4(0, 0, 0, 0);
+            if (active) {
+                const uint32_t i = list[j + (uint32_t)lane];
+                h = hits[base + i];
+                if (PRIMARY) {
+                    slot = chunk * ps.chunk + i;
+                    primary_sample(cam, ps, film_n, slot, pixel, sampleno, o, d);
+                } else {
+                    const float4 r0 = in_q[3 * (base + i)], r1 = in_q[3 * (base + i) + 1], r2 = in_q[3 * (base + i) + 2];
+                    o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+                    slot = __float_as_uint(r1.z); node = (__float_as_uint(r1.w) >> 8) & 0xFFFFu;
+                    pixel = __float_as_uint(r2.x); sampleno = __float_as_uint(r2.y);
+                }
+                hp = add3(o, sscale(h.x, d));                                          // mod.rs:212
+                const float4 nn = ((const float4*)sc.normals)[__float_as_uint(h.w)];   // calc_normal, mod.rs:198-205 (precomputed)
+                n = mk3(nn.x, nn.y, nn.z);
+                geom = __float_as_uint(nn.w);
+            }
+            // ---- shade() set-up per light, mod.rs:214-257; the shadow ray carries the finished term
+            for (uint32_t li = 0; li < sc.nlights; ++li) {
+                bool want = false;
+                f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 1), c = mk3(0, 0, 0);
+                if (active) {
+                    const DLight lt = sc.lights[li];
+                    const f3 l = sub3(mk3(lt.px, lt.py, lt.pz), hp);                   // mod.rs:215
+                    const f3 ln = normalized3(l);
+                    const float ndl = dot3(n, ln);                                     // mod.rs:216
+                    if (!(ndl < 0.0f)) {                                               // mod.rs:218
+                        want = true;
+                        so = add3(hp, vscale(l, 0.01f)); sd = l;                       // mod.rs:224-225
+                        const DMaterial m = sc.materials[geom];
+                        f3 diffuse = mk3(m.r, m.g, m.b);
+                        if (m.kind_tex & 0x80000000u) diffuse = fetch_texel(sc, m.kind_tex & 0x7FFFFFFFu, h.y, h.z);
+                        const f3 view = normalized3(d);                                // mod.rs:251
+                        const f3 refl = sub3(sscale(2.0f * ndl, n), ln);               // mod.rs:252-253
+                        const float spec = pow32(dot3(view, refl));                    // mod.rs:255, SPECULAR = white
+                        c = mk3((diffuse.x * ndl + spec) * lt.cr, (diffuse.y * ndl + spec) * lt.cg, (diffuse.z * ndl + spec) * lt.cb);
+                    }
+                }
+                uint32_t n_new;
+                const uint32_t oi = wave_append(want, out_back, n_new);
+                if (want && out_front + oi < ps.region) {
+                    const size_t r = base + (ps.region - 1u - oi);
+                    out_q[3 * r] = make_float4(so.x, so.y, so.z, sd.x);
+                    out_q[3 * r + 1] = make_float4(sd.y, sd.z, __uint_as_float(slot), __uint_as_float(1u | (level << 4) | (node << 8) | (li << 24)));
+                    out_q[3 * r + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+                }
+            }
+            // ---- reflection rays, mod.rs:146-158 + 178-196
+            if (level < ps.recursions) {
+                const uint32_t k = ps.spread * (ps.recursions - level);                // num_sub_rays, mod.rs:150
+                const uint32_t index_in_level = node - ps.level_first[level];
+                for (uint32_t ci = 0; ci < k; ++ci) {
+                    const uint32_t child_node = ps.level_first[level + 1] + index_in_level * k + ci;
+                    f3 bo = mk3(0, 0, 0), bd = mk3(0, 0, 1);
+                    if (active) {
+                        uint32_t h0 = pixel, h1 = sampleno, h2 = 1u + child_node, h3 = ps.seed;
+                        pcg4d(h0, h1, h2, h3);
+                        uint32_t jx = __umulhi(h0, 65535u);                            // uniform in [0, 65534], sample_generator.rs:32
+                        const float4* __restrict__ table = (const float4*)sc.table;
+                        float4 tv = table[jx];
+                        uint32_t guard = 0u;
+                        while (tv.x * n.x + tv.y * n.y + tv.z * n.z <= 0.0f && guard < kNumSamples) {   // mod.rs:187-189
+                            jx = (jx + 1u) % kSampleMax;                               // sample_generator.rs:27
+                            tv = table[jx];
+                            ++guard;
+                        }
+                        bd = mk3(tv.x, tv.y, tv.z);
+                        bo = add3(hp, sscale(0.00001f, bd));                           // mod.rs:192-193
+                    }
+                    uint32_t n_new;
+                    const uint32_t oi = wave_append(active, out_front, n_new);
+                    if (active && oi + out_back < ps.region + 0u) {
+                        const size_t r = base + oi;
+                        out_q[3 * r] = make_float4(bo.x, bo.y, bo.z, bd.x);
+                        out_q[3 * r + 1] = make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8)));
+                        out_q[3 * r + 2] = make_float4(__uint_as_float(pixel), __uint_as_float(sampleno), 0.0f, 0.0f);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (out_front + out_back > ps.region) { if (lane == 0) counters->overflow = 1u; out_front = 0u; out_back = 0u; }
+        if (lane == 0) out_counts[chunk] = make_uint2(out_front, out_back);
+        acc_bounce += out_front; acc_shadow += out_back; acc_hits += cnt;
     }
     if (lane == 0) {
-        if (acc_bounce) atomicAdd(&counters->bounce, (unsigned long long)acc_bounce);
-        if (acc_shadow) atomicAdd(&counters->shadow, (unsigned long long)acc_shadow);
+        DCounters* cs = &counters[wave % kShards];
+        if (acc_bounce) atomicAdd(&cs->bounce, acc_bounce);
+        if (acc_shadow) atomicAdd(&cs->shadow, acc_shadow);
+        if (PRIMARY && acc_hits) atomicAdd(&cs->primary_hits, acc_hits);
     }
 }
 
@@ -425,18 +415,19 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict
 __global__ __launch_bounds__(kBlock) void intersect_kernel(DScene sc, const float* __restrict__ rays6, uint32_t n, int shadow_mode,
                                                           float* tuv, uint32_t* prim, uint8_t* blocked)
 {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    extern __shared__ int s_stack[];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const f3 o = mk3(rays6[6ull * i], rays6[6ull * i + 1], rays6[6ull * i + 2]);
     const f3 d = mk3(rays6[6ull * i + 3], rays6[6ull * i + 4], rays6[6ull * i + 5]);
-    Hit h;
+    RayState rs;
     uint32_t a = 0, b = 0;
-    traverse<false>(sc, o, d, shadow_mode != 0, &s_stack[threadIdx.x], h, a, b);
-    if (shadow_mode) blocked[i] = h.occ == 1 ? 1 : 0;
+    ray_init(rs, o, d, shadow_mode != 0, sc.root);
+    ray_run<false>(sc, rs, &s_stack[threadIdx.x], kBlock, a, b);
+    if (shadow_mode) blocked[i] = rs.occ == 1 ? 1 : 0;
     else {
-        prim[i] = h.prim;
-        if (h.prim != 0xFFFFFFFFu) { tuv[3ull * i] = h.t; tuv[3ull * i + 1] = h.u; tuv[3ull * i + 2] = h.v; }
+        prim[i] = rs.prim;
+        if (rs.prim != kMiss) { tuv[3ull * i] = rs.t; tuv[3ull * i + 1] = rs.u; tuv[3ull * i + 2] = rs.v; }
     }
 }
 
@@ -457,36 +448,57 @@ hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, u
 }
 
 // ---- launchers --------------------------------------------------------------------------------
-static int g_trace_blocks_per_cu[4] = { 0, 0, 0, 0 };
+static size_t stack_bytes(uint32_t depth) { return (size_t)(depth ? depth : 1u) * kBlock * sizeof(int); }
 
 template <bool P, bool C>
-static int blocks_per_cu()
+static int trace_blocks_per_cu(size_t lds)
 {
-    int& cache = g_trace_blocks_per_cu[(P ? 2 : 0) + (C ? 1 : 0)];
-    if (cache == 0) {
+    // the occupancy query costs ~0.3 ms of host time: ask once per (kernel, LDS size)
+    static size_t cached_lds = ~(size_t)0;
+    static int cached_nb = 0;
+    if (cached_lds != lds) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_round_kernel<P, C>, kBlock, 0) != hipSuccess || nb < 1) nb = 1;
-        cache = nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<P, C>, kBlock, lds) != hipSuccess || nb < 1) nb = 1;
+        cached_nb = nb > 8 ? 8 : nb;
+        cached_lds = lds;
     }
-    return cache;
+    return cached_nb;
 }
 
-hipError_t launch_trace_round(hipStream_t stream, int num_cus, bool primary, bool count, const DScene& sc, const DCamera& cam, const DPass& ps,
-                              uint32_t level, const void* in_q, const uint32_t* in_count, void* out_q, uint32_t* out_count, uint32_t* cursor,
-                              float* slot_L, const uint32_t* film_n, DCounters* counters)
+hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, const DScene& sc, const DCamera& cam, const DPass& ps,
+                        const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
+                        float* slot_L, const uint32_t* film_n, DCounters* counters)
 {
-    // persistent grid: as many blocks as the chip holds; waves pull 64-ray chunks from `cursor`
-    int per_cu = primary ? (count ? blocks_per_cu<true, true>() : blocks_per_cu<true, false>())
-                         : (count ? blocks_per_cu<false, true>() : blocks_per_cu<false, false>());
+    // persistent grid: as many blocks as the chip holds; waves pull chunks from `cursor`
+    const size_t lds = stack_bytes(ps.stack_depth);
+    const int per_cu = primary ? (count ? trace_blocks_per_cu<true, true>(lds) : trace_blocks_per_cu<true, false>(lds))
+                               : (count ? trace_blocks_per_cu<false, true>(lds) : trace_blocks_per_cu<false, false>(lds));
     dim3 grid((unsigned)(num_cus * per_cu)), block(kBlock);
-    const float4* iq = (const float4*)in_q; float4* oq = (float4*)out_q;
+    const float4* iq = (const float4*)in_q; const uint2* ic = (const uint2*)in_counts; float4* hq = (float4*)hits;
     if (primary) {
-        if (count) hipLaunchKernelGGL((trace_round_kernel<true, true>), grid, block, 0, stream, sc, cam, ps, level, iq, in_count, oq, out_count, cursor, slot_L, film_n, counters);
-        else hipLaunchKernelGGL((trace_round_kernel<true, false>), grid, block, 0, stream, sc, cam, ps, level, iq, in_count, oq, out_count, cursor, slot_L, film_n, counters);
+        if (count) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
+        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
     } else {
-        if (count) hipLaunchKernelGGL((trace_round_kernel<false, true>), grid, block, 0, stream, sc, cam, ps, level, iq, in_count, oq, out_count, cursor, slot_L, film_n, counters);
-        else hipLaunchKernelGGL((trace_round_kernel<false, false>), grid, block, 0, stream, sc, cam, ps, level, iq, in_count, oq, out_count, cursor, slot_L, film_n, counters);
+        if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
+                        const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts,
+                        const uint32_t* film_n, DCounters* counters)
+{
+    const size_t lds = (size_t)ps.list_cap * kWavesPerBlock * sizeof(uint32_t);
+    unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned cap = (unsigned)num_cus * 8u;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    dim3 grid(blocks), block(kBlock);
+    if (primary) hipLaunchKernelGGL((shade_kernel<true>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
+                                    (const float4*)hits, (float4*)out_q, (uint2*)out_counts, film_n, counters);
+    else hipLaunchKernelGGL((shade_kernel<false>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
+                            (const float4*)hits, (float4*)out_q, (uint2*)out_counts, film_n, counters);
     return hipGetLastError();
 }
 
@@ -508,12 +520,12 @@ hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t nro
     return hipGetLastError();
 }
 
-hipError_t launch_intersect(hipStream_t stream, const DScene& sc, const float* rays6, uint32_t n, bool shadow_mode,
+hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack_depth, const float* rays6, uint32_t n, bool shadow_mode,
                             float* tuv, uint32_t* prim, uint8_t* blocked)
 {
     if (n == 0) return hipSuccess;
     dim3 block(kBlock), grid((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(intersect_kernel, grid, block, 0, stream, sc, rays6, n, shadow_mode ? 1 : 0, tuv, prim, blocked);
+    hipLaunchKernelGGL(intersect_kernel, grid, block, stack_bytes(stack_depth), stream, sc, rays6, n, shadow_mode ? 1 : 0, tuv, prim, blocked);
     return hipGetLastError();
 }
 

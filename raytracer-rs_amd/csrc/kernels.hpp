@@ -6,16 +6,18 @@
 
 namespace mi355rt {
 
-hipError_t launch_trace_round(hipStream_t stream, int num_cus, bool primary, bool count, const DScene& sc, const DCamera& cam, const DPass& ps,
-                              uint32_t level, const void* in_q, const uint32_t* in_count, void* out_q, uint32_t* out_count, uint32_t* cursor,
-                              float* slot_L, const uint32_t* film_n, DCounters* counters);
+hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, const DScene& sc, const DCamera& cam, const DPass& ps,
+                        const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
+                        float* slot_L, const uint32_t* film_n, DCounters* counters);
+hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
+                        const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts,
+                        const uint32_t* film_n, DCounters* counters);
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color);
 hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t nrows, uint32_t width, bool packed,
                           const float* film_sum, const uint32_t* film_n, uint32_t* out);
-hipError_t launch_intersect(hipStream_t stream, const DScene& sc, const float* rays6, uint32_t n, bool shadow_mode,
+hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack_depth, const float* rays6, uint32_t n, bool shadow_mode,
                             float* tuv, uint32_t* prim, uint8_t* blocked);
-
 hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, uint32_t n, float* q, float* r, float* p);
 
 }  // namespace mi355rt

@@ -1,6 +1,7 @@
 // renderer.cpp — see renderer.hpp.
 #include "renderer.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "kernels.hpp"
 
@@ -167,8 +168,8 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_all_rows_, all.data(), all.size() * 4)) return bail();
     if (!upload(d_owned_rows_, owned_rows.data(), owned_rows.size() * 4)) return bail();
     if (!upload(d_tmp_rows_, nullptr, 64 * 4)) return bail();
-    if (!upload(d_counters_, nullptr, sizeof(DCounters))) return bail();
-    if (!upload(d_ctrl_, nullptr, 16 * 4)) return bail();
+    if (!upload(d_counters_, nullptr, sizeof(DCounters) * kShards)) return bail();
+    if (!upload(d_ctrl_, nullptr, kMaxRounds * 64)) return bail();
     if (!upload(d_debug_color_, nullptr, 16)) return bail();
 
     // queue records one sample can put into one round's output queue (shadow rays of level l + rays of level l+1)
@@ -178,6 +179,11 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
         uint32_t nn = l < cfg.recursions ? level_first[l + 2] - level_first[l + 1] : 0;
         records_per_sample_ = std::max(records_per_sample_, nl * std::max(nlights_, 1u) + nn);
     }
+    max_level_nodes_ = 1;
+    for (uint32_t l = 0; l <= cfg.recursions; ++l) max_level_nodes_ = std::max(max_level_nodes_, level_first[l + 1] - level_first[l]);
+    chunk_ = 256;
+    if (const char* e = getenv("MI355RT_LEAF_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) leaf_threshold_ = (uint32_t)v; }
+    if (const char* e = getenv("MI355RT_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) chunk_ = (uint32_t)v; }
     code = MI355RT_OK;
     return true;
 }
@@ -190,6 +196,8 @@ Renderer::~Renderer()
     if (d_queue_[0]) (void)hipFree(d_queue_[0]);
     if (d_queue_[1]) (void)hipFree(d_queue_[1]);
     if (d_slot_L_) (void)hipFree(d_slot_L_);
+    for (int i = 0; i < 2; ++i) if (d_chunk_counts_[i]) (void)hipFree(d_chunk_counts_[i]);
+    if (d_hits_) (void)hipFree(d_hits_);
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -214,9 +222,16 @@ bool Renderer::ensure_pass_capacity(size_t nsamples)
     for (int i = 0; i < 2; ++i) if (d_queue_[i]) { (void)hipFree(d_queue_[i]); d_queue_[i] = nullptr; }
     if (d_slot_L_) { (void)hipFree(d_slot_L_); d_slot_L_ = nullptr; }
     pass_capacity_ = 0;
-    size_t records = nsamples * records_per_sample_;
-    if (records > 0x7FFFFFFFull) { last_error = "pass too large"; return false; }
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc(&d_queue_[i], records * kRayRecordBytes));
+    const size_t nchunks = (nsamples + chunk_ - 1) / chunk_;
+    const size_t records = nchunks * chunk_ * records_per_sample_;
+    if (nsamples > 0x7FFFFFFFull) { last_error = "pass too large"; return false; }
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc(&d_queue_[i], records * kRayRecordBytes));
+        if (d_chunk_counts_[i]) { (void)hipFree(d_chunk_counts_[i]); d_chunk_counts_[i] = nullptr; }
+        HIP_TRY(hipMalloc((void**)&d_chunk_counts_[i], nchunks * 8));
+    }
+    if (d_hits_) { (void)hipFree(d_hits_); d_hits_ = nullptr; }
+    HIP_TRY(hipMalloc(&d_hits_, records * 16));
     HIP_TRY(hipMalloc((void**)&d_slot_L_, nsamples * nodes_per_sample * std::max(nlights_, 1u) * 12));
     pass_capacity_ = nsamples;
     queue_records_ = records;
@@ -236,14 +251,19 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     ps.nodes_per_sample = nodes_per_sample;
     std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
     ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
-    ps.out_capacity = (uint32_t)queue_records_;
+    ps.chunk = chunk_; ps.nchunks = (uint32_t)((nsamples + chunk_ - 1) / chunk_); ps.region = chunk_ * records_per_sample_;
+    ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
+    ps.leaf_threshold = leaf_threshold_;
+    ps.pull_mode = nsamples >= ((size_t)16 << 20) ? 0u : 2u;
+    if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
     const DCamera cam = device_camera();
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
     const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
 
     HIP_TRY(hipMemsetAsync(d_slot_L_, 0, nsamples * nodes_per_sample * std::max(nlights_, 1u) * 12, stream_));
-    HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 16 * 4, stream_));
-    const uint32_t rounds = cfg.recursions + 2;      // levels 0..R, plus the shadow rays of level R
+    HIP_TRY(hipMemsetAsync(d_ctrl_, 0, kMaxRounds * 64, stream_));
+    // round r: trace the rays of level r (+ the shadow rays emitted by level r-1), then shade level r
+    const uint32_t rounds = cfg.recursions + 2;
     for (uint32_t r = 0; r < rounds; ++r) {
         if (timed) {
             if (ev_used_ + 2 > ev_pool_.size()) {
@@ -251,11 +271,13 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
             }
             HIP_TRY(hipEventRecord(ev_pool_[ev_used_], stream_));
         }
-        HIP_TRY(launch_trace_round(stream_, num_cus_, r == 0, count, dscene_, cam, ps, r,
-                                   r == 0 ? nullptr : d_queue_[(r - 1) & 1], d_ctrl_ + 8 + r, d_queue_[r & 1], d_ctrl_ + 8 + r + 1, d_ctrl_ + r,
-                                   d_slot_L_, d_film_n_, d_counters_));
+        const void* in_q = r == 0 ? nullptr : d_queue_[(r - 1) & 1];
+        const void* in_c = r == 0 ? nullptr : d_chunk_counts_[(r - 1) & 1];
+        HIP_TRY(launch_trace(stream_, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, d_hits_, d_ctrl_ + r * 16, d_slot_L_, d_film_n_, d_counters_));
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], stream_)); ev_used_ += 2; }
         ++launches_;
+        if (r <= cfg.recursions)
+            HIP_TRY(launch_shade(stream_, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, d_hits_, d_queue_[r & 1], d_chunk_counts_[r & 1], d_film_n_, d_counters_));
     }
     HIP_TRY(launch_resolve(stream_, ps, cfg.width, nlights_, d_slot_L_, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
     return true;
@@ -265,7 +287,7 @@ bool Renderer::begin_call()
 {
     if (!bind()) return false;
     ev_used_ = 0; launches_ = 0;
-    HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters), stream_));
+    HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
     HIP_TRY(hipEventRecord(ev_begin_, stream_));
     return true;
 }
@@ -274,8 +296,12 @@ bool Renderer::end_call(uint64_t primary)
 {
     HIP_TRY(hipEventRecord(ev_end_, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
-    DCounters c;
-    HIP_TRY(hipMemcpy(&c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
+    DCounters shard[kShards], c{};
+    HIP_TRY(hipMemcpy(shard, d_counters_, sizeof shard, hipMemcpyDeviceToHost));
+    for (const DCounters& s : shard) {
+        c.bounce += s.bounce; c.shadow += s.shadow; c.primary_hits += s.primary_hits;
+        c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
+    }
     counts = mi355rt_ray_counts{};
     counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
     counts.nodes_visited = c.nodes_visited; counts.tris_tested = c.tris_tested; counts.trace_launches = launches_;
@@ -323,7 +349,8 @@ bool Renderer::render(uint32_t spp)
     if (!begin_call()) return false;
     const uint32_t nrows = (uint32_t)owned_rows.size();
     if (nrows && spp) {
-        const size_t target = cfg.samples_per_pass ? (size_t)cfg.samples_per_pass * cfg.width * nrows : ((size_t)8 << 20);
+        size_t target = cfg.samples_per_pass ? (size_t)cfg.samples_per_pass * cfg.width * nrows : ((size_t)32 << 20);
+        if (const char* e = getenv("MI355RT_PASS_SAMPLES")) { long v = atol(e); if (v >= 1024) target = (size_t)v; }
         uint32_t rows_per_pass = (uint32_t)std::min<size_t>(nrows, std::max<size_t>(1, target / cfg.width));
         uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, target / ((size_t)rows_per_pass * cfg.width)));
         if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
@@ -393,7 +420,7 @@ bool Renderer::intersect(const float* rays6, size_t n, float* tuv, uint32_t* pri
     chk(hipMalloc((void**)&d_blocked, n), "hipMalloc blocked");
     if (ok) chk(hipMemcpyAsync(d_rays, rays6, n * 24, hipMemcpyHostToDevice, stream_), "upload rays");
     if (ok && !shadow) chk(hipMemcpyAsync(d_tuv, tuv, n * 12, hipMemcpyHostToDevice, stream_), "upload tuv");   // misses stay untouched
-    if (ok) chk(launch_intersect(stream_, dscene_, d_rays, (uint32_t)n, shadow, d_tuv, d_prim, d_blocked), "intersect kernel");
+    if (ok) chk(launch_intersect(stream_, dscene_, bvh.max_depth + 1, d_rays, (uint32_t)n, shadow, d_tuv, d_prim, d_blocked), "intersect kernel");
     if (ok && shadow) chk(hipMemcpyAsync(blocked, d_blocked, n, hipMemcpyDeviceToHost, stream_), "download blocked");
     if (ok && !shadow) {
         chk(hipMemcpyAsync(tuv, d_tuv, n * 12, hipMemcpyDeviceToHost, stream_), "download tuv");
@@ -427,7 +454,7 @@ bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, fl
 {
     if (!bind()) return false;
     if (nodes < nodes_per_sample || pixel >= cfg.width * cfg.height) { last_error = "bad debug_sample arguments"; return false; }
-    HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters), stream_));
+    HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
     ev_used_ = 0;
     if (!run_pass(nullptr, 0, 1, 1, true, pixel, sampleno)) return false;
     HIP_TRY(hipStreamSynchronize(stream_));

@@ -67,6 +67,11 @@ private:
     uint32_t* d_ctrl_ = nullptr;         // [0..7] cursors, [8..15] queue counts
     float* d_debug_color_ = nullptr;
     void* d_queue_[2] = { nullptr, nullptr };
+    uint32_t* d_chunk_counts_[2] = { nullptr, nullptr };   // rays per chunk in each queue
+    void* d_hits_ = nullptr;             // hit records of the round being processed (16 B per queue record)
+    uint32_t chunk_ = 256;               // primary samples per work chunk
+    uint32_t max_level_nodes_ = 1;
+    uint32_t leaf_threshold_ = 24;
     float* d_slot_L_ = nullptr;
     size_t pass_capacity_ = 0;           // samples
     size_t queue_records_ = 0;

@@ -1,0 +1,133 @@
+// traverse.hpp — per-lane BVH2 traversal state machine (included by kernels.hip only).
+//
+// Result semantics (what must match the reference):
+//   radiance rays: the TRUE closest hit — lowest t, ties to the lowest triangle index, i.e. the
+//     first in the reference's list order (no_acceleration_intersector.rs:13-41); the triangle test
+//     is Moller-Trumbore "late out" (intersect.rs:62-98) in the reference's operation order.
+//   shadow rays: only the predicate of mod.rs:226-229 is needed — "the CLOSEST hit has
+//     0.01 < t < 1.0".  Equivalent search: look in [0, 1); a hit in (0.01, 1) marks the ray blocked
+//     and shrinks the interval to [0, 0.01]; a hit with t <= 0.01 un-blocks it and ends the search.
+// The box tests are conservative (boxes are padded in bvh.cpp), so they never change a result.
+#pragma once
+#include "device_math.hpp"
+#include "device_types.hpp"
+
+namespace mi355rt {
+
+struct RayState {
+    f3 o, d;
+    float idx, idy, idz;   // 1/d (approximate reciprocal: only the padded box tests use it)
+    float tlimit;          // only hits with t <= tlimit can still change the result
+    float t, u, v;
+    uint32_t prim;         // 0xFFFFFFFF = no hit yet
+    int node;              // >= 0 inner node, < 0 leaf code
+    uint32_t tri;          // next triangle of the current leaf
+    int sp;
+    int occ;               // shadow rays: 0 nothing, 1 blocked, 2 unblocked by a hit at t <= 0.01
+    bool shadow;
+};
+
+__device__ __forceinline__ void ray_init(RayState& s, f3 o, f3 d, bool shadow, int root)
+{
+    s.o = o; s.d = d;
+    s.idx = __builtin_amdgcn_rcpf(d.x); s.idy = __builtin_amdgcn_rcpf(d.y); s.idz = __builtin_amdgcn_rcpf(d.z);
+    s.tlimit = shadow ? 0x1.fffffep-1f : __builtin_inff();     // shadow: t < 1.0
+    s.t = __builtin_inff(); s.u = 0.0f; s.v = 0.0f; s.prim = 0xFFFFFFFFu;
+    s.node = root; s.tri = 0u; s.sp = 0; s.occ = 0; s.shadow = shadow;
+}
+
+// Pop the next deferred node; returns true when the stack is empty (ray finished).
+__device__ __forceinline__ bool ray_pop(RayState& s, const int* stack, int stride)
+{
+    if (s.sp == 0) return true;
+    --s.sp;
+    s.node = stack[s.sp * stride];
+    s.tri = 0u;
+    return false;
+}
+
+// One inner-node step (s.node >= 0): test both child boxes, descend into the nearer hit child and
+// defer the other.  `stack` points at this lane's column of an LDS array with row stride `stride`
+// ints.  Returns true when the ray is finished.
+template <bool COUNT>
+__device__ __forceinline__ bool inner_step(const DScene& sc, RayState& s, int* stack, int stride, uint32_t& n_nodes)
+{
+    const float4* __restrict__ nodes = (const float4*)sc.nodes;
+    if (COUNT) ++n_nodes;
+    const float4 q0 = nodes[4 * s.node], q1 = nodes[4 * s.node + 1], q2 = nodes[4 * s.node + 2];
+    const float4 q3 = nodes[4 * s.node + 3];
+    float a1 = (q0.x - s.o.x) * s.idx, a2 = (q0.y - s.o.x) * s.idx;
+    float b1 = (q0.z - s.o.y) * s.idy, b2 = (q0.w - s.o.y) * s.idy;
+    float c1 = (q2.x - s.o.z) * s.idz, c2 = (q2.y - s.o.z) * s.idz;
+    const float tn0 = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
+    const float tf0 = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), s.tlimit));
+    a1 = (q1.x - s.o.x) * s.idx; a2 = (q1.y - s.o.x) * s.idx;
+    b1 = (q1.z - s.o.y) * s.idy; b2 = (q1.w - s.o.y) * s.idy;
+    c1 = (q2.z - s.o.z) * s.idz; c2 = (q2.w - s.o.z) * s.idz;
+    const float tn1 = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
+    const float tf1 = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), s.tlimit));
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+    const int c0i = __float_as_int(q3.x), c1i = __float_as_int(q3.y);
+    s.tri = 0u;
+    if (h0 && h1) {
+        const bool sw = tn1 < tn0;
+        stack[s.sp * stride] = sw ? c0i : c1i;
+        ++s.sp;
+        s.node = sw ? c1i : c0i;
+        return false;
+    }
+    if (h0) { s.node = c0i; return false; }
+    if (h1) { s.node = c1i; return false; }
+    return ray_pop(s, stack, stride);
+}
+
+// One leaf step (s.node < 0): test triangle s.tri of the leaf, then advance; after the last triangle
+// pop the next deferred node.  Returns true when the ray is finished.
+template <bool COUNT>
+__device__ __forceinline__ bool leaf_step(const DScene& sc, RayState& s, const int* stack, int stride, uint32_t& n_tris)
+{
+    const float4* __restrict__ tris = (const float4*)sc.tris;
+    const uint32_t code = ~(uint32_t)s.node;
+    const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+    if (COUNT) ++n_tris;
+    const uint32_t ti = first + s.tri;
+    const float4 t0 = tris[3 * ti], t1 = tris[3 * ti + 1], t2 = tris[3 * ti + 2];
+    ++s.tri;
+    // Moller-Trumbore "late out", intersect.rs:62-98, same operation order
+    const f3 v0 = mk3(t0.x, t0.y, t0.z), v0v1 = mk3(t1.x, t1.y, t1.z), v0v2 = mk3(t2.x, t2.y, t2.z);
+    const f3 pvec = cross3(s.d, v0v2);
+    const float det = dot3(v0v1, pvec);
+    if (!(fabsf(det) < 1.1920929e-7f)) {                       // f32::EPSILON
+        const float inv_det = div_rn(1.0f, det);
+        const f3 tvec = sub3(s.o, v0);
+        const float u = dot3(tvec, pvec) * inv_det;
+        const f3 qvec = cross3(tvec, v0v1);
+        const float v = dot3(s.d, qvec) * inv_det;
+        const float t = dot3(v0v2, qvec) * inv_det;
+        if (!(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && !(t < 0.0f)) {
+            const uint32_t prim = __float_as_uint(t0.w);
+            if (!s.shadow) {
+                if (s.prim == 0xFFFFFFFFu || t < s.t || (t == s.t && prim < s.prim)) {
+                    s.t = t; s.u = u; s.v = v; s.prim = prim; s.tlimit = t;
+                }
+            } else if (t <= s.tlimit) {
+                if (t > 0.01f) { s.occ = 1; s.tlimit = 0.01f; }
+                else { s.occ = 2; return true; }
+            }
+        }
+    }
+    if (s.tri < cnt) return false;
+    return ray_pop(s, stack, stride);
+}
+
+// whole-ray traversal (used by the batched Intersector seam)
+template <bool COUNT>
+__device__ __forceinline__ void ray_run(const DScene& sc, RayState& s, int* stack, int stride, uint32_t& n_nodes, uint32_t& n_tris)
+{
+    for (;;) {
+        const bool done = s.node >= 0 ? inner_step<COUNT>(sc, s, stack, stride, n_nodes) : leaf_step<COUNT>(sc, s, stack, stride, n_tris);
+        if (done) break;
+    }
+}
+
+}  // namespace mi355rt

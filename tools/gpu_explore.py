@@ -12,7 +12,7 @@ for name in names:
     sc = sio.load_scene_file(os.path.join(ge.SCENES, name + ".scene"))
     rt = pkg.create_raytracer_from_arrays(sc, 70, 1920, 1080, seed=1, flags=flags)
     print(name, rt.accel_stats(), flush=True)
-    for it in range(3):
+    for it in range(int(os.environ.get("ITERS", "3"))):
         t = time.time(); c = rt.render(spp); dt = time.time() - t
         d = c.as_dict()
         print("%s spp=%d wall %.1f ms  gpu %.1f ms trace %.1f ms  rays %.1fM (p %.1fM b %.1fM s %.1fM) -> %.1f Mrays/s total, %.1f Mprimary/s  nodes/ray %.1f tris/ray %.1f" % (
