@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on MI355X.
+
+A "step" is one frame of the render hot path: thai2 (20 049 triangles) at 1920x1080, 64 samples per
+pixel per GPU, RECURSIONS = 2 / SUB_SPREAD = 1, the reference's own pixel->ray mapping, seed 1,
+followed by the tonemapped read-out into device memory and (N > 1) the RCCL gather of the row
+stripes to every rank.  Scene, BVH and film are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Weak scaling: every GPU traces 1920*1080*64 primary samples.  With N GPUs the frame is the same
+1920x1080 image at 64*N spp, rows dealt to the ranks in stripes of 8 (mi355rt_config.stripe_*), so
+each rank owns 1/N of the rows at N times the spp.  The counter RNG is keyed by (pixel, sample#), so
+the image is the one a single GPU would produce.  No collective on the data path; one
+all_gather of the packed u32 stripes per frame.
+
+Rank 0 prints ONE JSON line (see the repo instructions for the contract).  Extra objects:
+  roofline      dominant kernel = trace_kernel (closest-hit traversal).  achieved = algorithmic bytes
+                (64 B x nodes visited + 48 B x triangles tested + 96 B per ray, the
+                step counts measured live by the instrumented kernel variant) / summed HIP-event time of
+                the trace launches of the timed frames.  peak = 8000 GB/s (HBM3E spec).  The scene is
+                cache-resident, so this is a LOGICAL rate, not HBM traffic.
+  cpu_baseline  the CPU oracle (C restatement of the reference: octree, recursive radiance) timed on this
+                box's host cores on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCENE = "thai2"
+WIDTH, HEIGHT, SPP = 1920, 1080, 64
+STRIPE_ROWS = 8
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default=SCENE)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_package()
+    import importlib
+    scene_io = importlib.import_module("raytracer_rs_amd.scene_io")
+    scene = scene_io.load_scene_file(os.path.join(ge.SCENES, args.scene + ".scene"))
+    spp = args.spp * world
+    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, WIDTH, HEIGHT, seed=1, device=local_rank,
+                                          stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_world=world,
+                                          flags=pkg.FLAG_TIME_KERNELS)
+    stripes = importlib.import_module("raytracer_rs_amd.stripes")
+    rows = rt.owned_rows()
+    assert list(rows) == stripes.owned_rows(HEIGHT, STRIPE_ROWS, rank, world)
+    fg = stripes.FrameGather(HEIGHT, WIDTH, STRIPE_ROWS, world, "cuda")
+    stripe = fg.stripe_buffer("cuda")
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        rt.film.clear()
+        counts = rt.render(spp)                                   # synchronous: returns when the frame is traced
+        rt.tonemap_owned_rows_device(stripe.data_ptr(), rows.size * WIDTH)
+        fg.gather(dist, stripe)                                    # every rank ends up with the full frame
+        return counts
+
+    # instrumented frame (untimed): BVH nodes visited / triangles tested per ray for the roofline figure
+    rt.set_flags(pkg.FLAG_COUNT_STEPS)
+    rt.film.clear()
+    c = rt.render(max(1, min(4, spp)))
+    nodes_per_ray = c.nodes_visited / max(1, c.primary + c.bounce + c.shadow)
+    tris_per_ray = c.tris_tested / max(1, c.primary + c.bounce + c.shadow)
+    rt.set_flags(pkg.FLAG_TIME_KERNELS)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    tot = dict(primary=0, bounce=0, shadow=0, trace_ms=0.0, launches=0, gpu_ms=0.0)
+    for _ in range(args.steps):
+        c = step()
+        tot["primary"] += c.primary; tot["bounce"] += c.bounce; tot["shadow"] += c.shadow
+        tot["trace_ms"] += c.trace_ms; tot["launches"] += c.trace_launches; tot["gpu_ms"] += c.total_ms
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, tot["primary"], tot["bounce"], tot["shadow"], tot["trace_ms"], tot["launches"]],
+                         dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = stats[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0]); vals = [float(x) for x in sums]
+    else:
+        vals = [float(x) for x in stats[1:]]
+    primary, bounce, shadow, trace_ms, launches = vals
+    total_rays = primary + bounce + shadow
+
+    if rank == 0:
+        bytes_per_ray = 64.0 * nodes_per_ray + 48.0 * tris_per_ray + 96.0
+        # trace_ms is summed over ranks and total_rays too: the ratio is the per-GPU logical rate
+        achieved = total_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (whole node) + ms/frame, 1920x1080x64spp thai2.dae",
+            "value": round(total_rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s 1920x1080, %d spp per GPU (frame = %d spp), recursions 2 / spread 1, reference pixel mapping, "
+                                   "rows dealt in stripes of %d" % (args.scene, args.spp, spp, STRIPE_ROWS),
+                       "scene": args.scene, "width": WIDTH, "height": HEIGHT, "spp_per_gpu": args.spp, "seed": 1,
+                       "parallelism": "row stripes x%d, RCCL all_gather of u32 stripes" % world},
+            "primary_mrays_per_s": round(primary / elapsed / 1e6, 2),
+            "rays_per_frame": {"primary": primary / args.steps, "bounce": bounce / args.steps, "shadow": shadow / args.steps},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "trace_kernel", "launches": int(launches), "avg_launch_ms": round(trace_ms / max(launches, 1), 4),
+                         "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                         "note": "logical bytes (SURVEY.md 8d); the 1.5 MB scene is cache-resident, measured HBM traffic is queues + film only"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ge, scene)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ge, scene):
+    """The oracle (oracle/oracle.c) on this box's host cores, bounded sample of the same workload."""
+    O = ge.load_oracle()
+    ncores = min(os.cpu_count() or 1, 64)
+    orc = O.Oracle(scene, WIDTH, HEIGHT, seed=1)
+    # whole 1920x1080 frames at 1 spp, repeated until ~12 s of wall time have been spent
+    t0 = time.perf_counter()
+    tot = dict(primary=0, bounce=0, shadow=0)
+    frames = 0
+    while True:
+        c = orc.render(1, nthreads=ncores)
+        frames += 1
+        for k in tot:
+            tot[k] += c[k]
+        if time.perf_counter() - t0 >= 12.0 or frames >= 64:
+            break
+    dt = time.perf_counter() - t0
+    rays = tot["primary"] + tot["bounce"] + tot["shadow"]
+    # single-thread rate on a smaller sample (the reference's real threading model, mod.rs:80-117)
+    t1 = time.perf_counter()
+    c1 = orc.render(1, nthreads=1, rows=(536, 544))
+    dt1 = time.perf_counter() - t1
+    rays1 = c1["primary"] + c1["bounce"] + c1["shadow"]
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": ncores, "kind": "port",
+            "sample": "%d spp of the same 1920x1080 thai2 frame (%d primary samples, %.1f s), octree oracle at 70 tris/leaf, %d threads; "
+                      "single_thread_value = 8 rows x 1 spp on 1 thread" % (frames, tot["primary"], dt, ncores),
+            "primary_mrays_per_s": round(tot["primary"] / dt / 1e6, 4),
+            "single_thread_value": round(rays1 / dt1 / 1e6, 4)}
+
+
+if __name__ == "__main__":
+    main()

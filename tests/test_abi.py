@@ -1,0 +1,82 @@
+"""The C-ABI boundary without a GPU: libmi355rt.so loads, exports every symbol include/mi355rt.h
+declares, the ctypes mirror covers exactly those symbols, struct layouts agree with the header, and
+creation fails LOUDLY without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi355rt.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.lib()
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(n for n, _, _ in pkg.ABI) == names
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (mi355rt_[a-z0-9_]+)", out))
+    assert exported == set(names)
+
+
+def test_struct_layouts_match_the_header(pkg, tmp_path):
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mi355rt.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(mi355rt_material),sizeof(mi355rt_light),sizeof(mi355rt_texture),sizeof(mi355rt_scene_desc),'
+                   'sizeof(mi355rt_config),sizeof(mi355rt_ray_counts),offsetof(mi355rt_config,seed),offsetof(mi355rt_scene_desc,camera_orientation));return 0;}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert got == [C.sizeof(pkg.Material), C.sizeof(pkg.Light), C.sizeof(pkg.Texture), C.sizeof(pkg.SceneDesc), C.sizeof(pkg.Config),
+                   C.sizeof(pkg.RayCounts), pkg.Config.seed.offset, pkg.SceneDesc.camera_orientation.offset]
+
+
+def test_default_config_matches_the_reference_defaults(pkg):
+    cfg = pkg.Config()
+    pkg.lib().mi355rt_default_config(C.byref(cfg))
+    assert (cfg.width, cfg.height) == (1024, 768)                 # main.rs:13-14
+    assert cfg.triangles_per_leaf == pkg.DEFAULT_TRIANGLES_PER_LEAF == 70
+    assert (cfg.recursions, cfg.spread) == (2, 1)                 # mod.rs:81-82
+
+
+def no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not no_gpu(), reason="checks the no-device error path")
+def test_create_without_a_gpu_fails_loudly(pkg, scenes):
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        pkg.create_raytracer_from_arrays(scenes("4boxes"), 70, 32, 32)
+
+
+def test_bad_arguments_are_rejected_before_touching_the_device(pkg, scenes):
+    sc = dict(scenes("4boxes"))
+    with pytest.raises(RuntimeError, match="width and height"):
+        pkg.create_raytracer_from_arrays(sc, 70, 0, 32)
+    with pytest.raises(RuntimeError, match="recursions"):
+        pkg.create_raytracer_from_arrays(sc, 70, 32, 32, recursions=9)
+    bad = dict(sc); bad["tri_geom"] = sc["tri_geom"] + 100
+    with pytest.raises(RuntimeError, match="out of range"):
+        pkg.create_raytracer_from_arrays(bad, 70, 32, 32)
+    with pytest.raises(RuntimeError, match="stripe_rank"):
+        pkg.create_raytracer_from_arrays(sc, 70, 32, 32, stripe_rank=3, stripe_world=2)
+
+
+def test_null_handle_calls_are_safe(pkg):
+    lib = pkg.lib()
+    assert lib.mi355rt_trace_frame_additive(None) == 0
+    assert lib.mi355rt_render(None, 1, None) == -1
+    assert lib.mi355rt_width(None) == 0
+    lib.mi355rt_destroy(None)

@@ -1,0 +1,79 @@
+"""Host-side logic that needs no GPU: stats strings, scene container, stripe decomposition and the
+frame gather over two gloo ranks (the N > 1 path of bench.py)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stats_strings(pkg):
+    st = pkg.stats.Stats()
+    s = st.stats(96000)                                                    # stats.rs:21-31
+    assert re.fullmatch(r"fps: [0-9.e+]+  primary rays/s: \d+", s)
+    st.stats(96000)
+    assert re.fullmatch(r"mean fps: [0-9.e+]+  mean primary rays/s: [0-9.e+]+", st.mean_stats())
+    assert st.num_measurements == 2
+
+
+def test_scene_container_roundtrip(scene_io, scenes):
+    for name, ntri, ngeom in (("4boxes", 48, 4), ("ico2", 608, 5), ("thai2", 20049, 2), ("ico3_tex", 608, 5)):
+        sc = scenes(name)
+        assert sc["tri_verts"].shape == (ntri, 9) and sc["tri_geom"].shape == (ntri,)
+        assert len(sc["mat_kind"]) == ngeom and sc["tri_geom"].max() == ngeom - 1
+        assert np.all(np.diff(sc["tri_geom"].astype(np.int64)) >= 0)       # geometry order = visual-scene node order
+        assert sc["lights"].shape == (1, 6) and len(sc["cameras"]) == 1
+    tex = scenes("ico3_tex")["textures"]
+    assert len(tex) == 1 and tex[0].shape == (640, 640, 3) and tex[0].max() < 1.0
+    assert np.array_equal(tex[0] * 256.0, np.round(tex[0] * 256.0))        # texels are byte/256 exactly
+
+
+def test_stripe_partition_properties(pkg):
+    import importlib
+    st = importlib.import_module("raytracer_rs_amd.stripes")
+    for h, sr, world in ((1080, 8, 1), (1080, 8, 2), (1080, 8, 8), (2160, 16, 8), (50, 4, 3), (7, 8, 4)):
+        rows = [st.owned_rows(h, sr, r, world) for r in range(world)]
+        assert sorted(sum(rows, [])) == list(range(h))                      # a partition of the frame
+        assert max(len(r) for r in rows) <= st.max_owned_rows(h, sr, world)
+        assert max(len(r) for r in rows) - min(len(r) for r in rows) <= sr   # balanced to one stripe
+
+
+def _gather_worker(rank, world, port, h, w, sr, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    ge.load_package()
+    st = importlib.import_module("raytracer_rs_amd.stripes")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    fg = st.FrameGather(h, w, sr, world, "cpu")
+    stripe = fg.stripe_buffer("cpu")
+    rows = st.owned_rows(h, sr, rank, world)
+    vals = (torch.tensor(rows, dtype=torch.int32)[:, None] * 100000 + torch.arange(w, dtype=torch.int32)[None, :])
+    stripe.view(fg.max_rows, w)[: len(rows)] = vals
+    frame = fg.gather(dist, stripe).view(h, w)
+    expect = torch.arange(h, dtype=torch.int32)[:, None] * 100000 + torch.arange(w, dtype=torch.int32)[None, :]
+    q.put((rank, bool(torch.equal(frame, expect))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h,w,sr", [(2, 50, 16, 8), (3, 37, 5, 4)])
+def test_frame_gather_over_gloo_ranks(world, h, w, sr):
+    """one process per rank, gloo on 127.0.0.1: every rank ends up with the full frame, rows in place."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, h, w, sr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(world)]
