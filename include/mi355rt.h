@@ -37,6 +37,11 @@ extern "C" {
 #define MI355RT_FLAG_FIX_ROW_INDEX  1u  /* v = idx / width instead of the reference's idx / height (mod.rs:93-96) */
 #define MI355RT_FLAG_COUNT_STEPS    2u  /* instrumented traversal: count BVH nodes visited / triangles tested */
 #define MI355RT_FLAG_TIME_KERNELS   4u  /* bracket every trace-kernel launch with HIP events */
+/* CREATE-time flag: intersect with the reference's own octree (built with config.triangles_per_leaf),
+ * traversal bug for bug (oct_tree_intersector.rs:148-206: sorted front-to-back children, first leaf
+ * whose closest triangle's hit point lies inside the leaf cube wins).  A slow parity path; without it
+ * the BVH returns the true closest hit (no_acceleration_intersector.rs semantics). */
+#define MI355RT_FLAG_OCTREE_SEMANTICS 8u
 
 typedef struct mi355rt_handle mi355rt_handle;
 
@@ -185,6 +190,9 @@ uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,
  * [4] node bytes, [5] triangle bytes, [6] nodes staged in LDS, [7] reserved */
 int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8]);
+/* reference-exact mode only: out[0] octree nodes, [1] inner, [2] leaves, [3] empty leaves, [4] depth,
+ * [5] triangle references (the quantities of SURVEY.md 6.2) */
+int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8]);
 uint32_t mi355rt_width(const mi355rt_handle* h);
 uint32_t mi355rt_height(const mi355rt_handle* h);
 uint32_t mi355rt_triangle_count(const mi355rt_handle* h);

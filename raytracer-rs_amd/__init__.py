@@ -28,6 +28,7 @@ DEFAULT_TRIANGLES_PER_LEAF = 70
 FLAG_FIX_ROW_INDEX = 1
 FLAG_COUNT_STEPS = 2
 FLAG_TIME_KERNELS = 4
+FLAG_OCTREE_SEMANTICS = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
@@ -116,6 +117,7 @@ ABI = [
     ("mi355rt_debug_numerics", C.c_int, [_H, _F, _F, C.c_size_t, _F, _F, _F]),
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
+    ("mi355rt_octree_stats", C.c_int, [_H, _U]),
     ("mi355rt_width", C.c_uint32, [_H]),
     ("mi355rt_height", C.c_uint32, [_H]),
     ("mi355rt_triangle_count", C.c_uint32, [_H]),
@@ -313,6 +315,11 @@ class RayTracer:
         self._check(lib().mi355rt_accel_stats(self._h, _up(out)))
         return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), max_leaf=int(out[3]),
                     node_bytes=int(out[4]), tri_bytes=int(out[5]), lds_nodes=int(out[6]))
+
+    def octree_stats(self):
+        out = np.zeros(8, np.uint32)
+        self._check(lib().mi355rt_octree_stats(self._h, _up(out)))
+        return dict(nodes=int(out[0]), inner=int(out[1]), leaves=int(out[2]), empty=int(out[3]), depth=int(out[4]), tri_refs=int(out[5]))
 
     @property
     def triangle_count(self):

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <queue>
+#include <cstdlib>
 
 namespace mi355rt {
 namespace {
@@ -22,6 +23,9 @@ struct Box {
 
 struct TmpNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; uint32_t depth = 0; };
 
+static uint32_t g_max_leaf = kBvhMaxLeaf;
+static float g_trav_cost = 1.5f;
+
 struct Builder {
     const float* verts;
     std::vector<Box> tri_box;
@@ -32,7 +36,7 @@ struct Builder {
     static uint32_t levels_needed(uint32_t n)
     {
         uint32_t l = 0;
-        while ((kBvhMaxLeaf << l) < n) ++l;
+        while ((g_max_leaf << l) < n) ++l;
         return l;
     }
 
@@ -71,10 +75,10 @@ struct Builder {
                 }
             }
         }
-        if (count <= kBvhMaxLeaf) {
+        if (count <= g_max_leaf) {
             // leaf unless the split is clearly cheaper (traversal step ~ 1.5 triangle tests)
             float leaf_cost = node.box.half_area() * (float)count;
-            float split_cost = best_axis >= 0 ? best_cost + 1.5f * node.box.half_area() : 3.4e38f;
+            float split_cost = best_axis >= 0 ? best_cost + g_trav_cost * node.box.half_area() : 3.4e38f;
             if (!(split_cost < leaf_cost)) return idx;
         }
         uint32_t mid;
@@ -111,6 +115,9 @@ int32_t leaf_code(uint32_t first, uint32_t count) { return ~(int32_t)((first << 
 void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out)
 {
     out = Bvh();
+    g_max_leaf = kBvhMaxLeaf; g_trav_cost = 1.5f;
+    if (const char* e = std::getenv("MI355RT_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) g_max_leaf = (uint32_t)v; }
+    if (const char* e = std::getenv("MI355RT_TRAV_COST")) { float v = (float)std::atof(e); if (v >= 0.0f) g_trav_cost = v; }
     if (ntri == 0) {
         // one empty leaf is not representable (count >= 1): a degenerate triangle that can never
         // be hit (|det| < EPSILON) keeps the kernels free of an "empty scene" special case

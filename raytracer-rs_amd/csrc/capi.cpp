@@ -267,6 +267,12 @@ int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8])
     out[6] = 0; out[7] = 0;
     return MI355RT_OK;
 }
+int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8])
+{
+    if (!h || !out) return MI355RT_E_INVALID;
+    std::memcpy(out, h->r->oct_stats_, sizeof h->r->oct_stats_);
+    return MI355RT_OK;
+}
 uint32_t mi355rt_width(const mi355rt_handle* h) { return h ? h->r->cfg.width : 0u; }
 uint32_t mi355rt_height(const mi355rt_handle* h) { return h ? h->r->cfg.height : 0u; }
 uint32_t mi355rt_triangle_count(const mi355rt_handle* h) { return h ? h->r->ntri : 0u; }

@@ -30,6 +30,9 @@ struct DScene {
     const DTexture* textures;
     const float* texels;      // RGB f32 pool
     const void* table;        // float4[65536] unit vectors
+    const void* oct_nodes;    // OctNodeFlat[] (reference-exact intersector only, else null)
+    const uint32_t* oct_leaf_tris;
+    const void* prim_tris;    // BvhTri[] in ORIGINAL triangle order (reference-exact intersector only)
     int32_t root;
     uint32_t nlights;
     uint32_t ntri;
@@ -61,6 +64,7 @@ struct DPass {
     uint32_t region;          // queue records reserved per chunk = chunk * worst-case records per sample
     uint32_t stack_depth;     // traversal stack rows in LDS (BVH max depth + 1)
     uint32_t leaf_threshold;  // trace kernel: run the triangle code once this many lanes wait at a leaf
+    uint32_t refill_threshold; // trace kernel: refill idle lanes once this many are idle
     uint32_t pull_mode;       // work distribution experiment switch (1 = default)
     uint32_t list_cap;        // shade kernel: LDS hit-list entries per wave (max radiance rays per chunk)
 };

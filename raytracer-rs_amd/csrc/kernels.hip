@@ -135,12 +135,17 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
     // lane state
     bool busy = false;
     RayState rs;
-    size_t rec = 0;                                  // radiance: hit-record index; shadow: queue record index
+    size_t rec = 0;                                  // radiance: hit-record index; shadow: float index into slot_L
+    f3 sh_L = mk3(0, 0, 0);                          // shadow: the light term the ray carries
     ray_init(rs, mk3(0, 0, 0), mk3(0, 0, 1), false, sc.root);
 
     for (;;) {
         // ---- refill idle lanes from the current chunk (pull a new chunk when it runs dry)
+        // A refill makes the wave wait for ray records that come from HBM, so it is done only when
+        // at least ps.refill_threshold lanes are idle (or nothing is left to do): the other waves of
+        // the SIMD then have enough work to cover the wait.
         unsigned long long idle = __ballot(!busy);
+        if ((uint32_t)__popcll(idle) < ps.refill_threshold && idle != ~0ull) idle = 0ull;
         while (idle != 0ull && !exhausted) {
             if (w_next >= w_ntot) {
                 uint32_t c = 0u;
@@ -167,6 +172,12 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
                     shadow = i >= w_nrad;
                     rec = r;
+                    if (shadow) {       // keep what the finish needs in registers: no load when the ray ends
+                        const float4 r2 = in_q[3 * r + 2];
+                        sh_L = mk3(r2.x, r2.y, r2.z);
+                        const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
+                        rec = 3ull * (((size_t)slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
+                    }
                 }
                 ray_init(rs, o, d, shadow, sc.root);
                 busy = true;
@@ -193,11 +204,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
             if (!rs.shadow) {
                 hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
             } else if (rs.occ != 1) {                                  // not blocked, mod.rs:232
-                const float4 r1 = in_q[3 * rec + 1], r2 = in_q[3 * rec + 2];
-                const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
-                const uint32_t node = (meta >> 8) & 0xFFFFu, light = meta >> 24;
-                float* dst = slot_L + 3ull * (((size_t)slot * ps.nodes_per_sample + node) * sc.nlights + light);
-                dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+                float* dst = slot_L + rec;
+                dst[0] = sh_L.x; dst[1] = sh_L.y; dst[2] = sh_L.z;
             }
         }
     }
@@ -205,6 +213,44 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
         for (int off = 32; off > 0; off >>= 1) { acc_nodes += __shfl_down((int)acc_nodes, off, 64); acc_tris += __shfl_down((int)acc_tris, off, 64); }
         DCounters* cs = &counters[global_wave_id() % kShards];
         if (lane_id() == 0) { atomicAdd(&cs->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&cs->tris_tested, (unsigned long long)acc_tris); }
+    }
+}
+
+// ---- trace with the reference-exact octree intersector (parity path, MI355RT_FLAG_OCTREE_SEMANTICS) ----
+template <bool PRIMARY>
+__global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera cam, DPass ps,
+                                                             const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                                             float4* __restrict__ hits, float* __restrict__ slot_L,
+                                                             const uint32_t* __restrict__ film_n)
+{
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    for (uint32_t chunk = global_wave_id(); chunk < ps.nchunks; chunk += nwaves) {
+        uint32_t n_rad, n_tot;
+        if (PRIMARY) { n_rad = min(ps.chunk, ps.nsamples - chunk * ps.chunk); n_tot = n_rad; }
+        else { const uint2 n = in_counts[chunk]; n_rad = n.x; n_tot = n.x + n.y; }
+        for (uint32_t i = (uint32_t)lane_id(); i < n_tot; i += 64u) {
+            f3 o, d;
+            size_t r = 0;
+            if (PRIMARY) {
+                uint32_t pixel, sampleno;
+                primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
+                r = (size_t)chunk * ps.region + i;
+            } else {
+                r = record_index(ps, chunk, i, n_rad);
+                const float4 r0 = in_q[3 * r], r1 = in_q[3 * r + 1];
+                o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+            }
+            float t, u, v; uint32_t prim;
+            octree_intersect(sc, o, d, t, u, v, prim);
+            if (i < n_rad) {
+                hits[r] = make_float4(t, u, v, __uint_as_float(prim));
+            } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {          // not blocked, mod.rs:226-232
+                const float4 r1 = in_q[3 * r + 1], r2 = in_q[3 * r + 2];
+                const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
+                float* dst = slot_L + 3ull * (((size_t)slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
+                dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+            }
+        }
     }
 }
 
@@ -420,6 +466,16 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(DScene sc, const floa
     if (i >= n) return;
     const f3 o = mk3(rays6[6ull * i], rays6[6ull * i + 1], rays6[6ull * i + 2]);
     const f3 d = mk3(rays6[6ull * i + 3], rays6[6ull * i + 4], rays6[6ull * i + 5]);
+    if (sc.oct_nodes) {          // reference-exact intersector
+        float t, u, v; uint32_t p;
+        octree_intersect(sc, o, d, t, u, v, p);
+        if (shadow_mode) blocked[i] = (p != kMiss && t > 0.01f && t < 1.0f) ? 1 : 0;
+        else {
+            prim[i] = p;
+            if (p != kMiss) { tuv[3ull * i] = t; tuv[3ull * i + 1] = u; tuv[3ull * i + 2] = v; }
+        }
+        return;
+    }
     RayState rs;
     uint32_t a = 0, b = 0;
     ray_init(rs, o, d, shadow_mode != 0, sc.root);
@@ -482,6 +538,19 @@ hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool coun
         if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
         else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
+                               const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n)
+{
+    unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned cap = (unsigned)num_cus * 4u;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    dim3 grid(blocks), block(kBlock);
+    if (primary) hipLaunchKernelGGL((trace_octree_kernel<true>), grid, block, 0, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);
+    else hipLaunchKernelGGL((trace_octree_kernel<false>), grid, block, 0, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);
     return hipGetLastError();
 }
 

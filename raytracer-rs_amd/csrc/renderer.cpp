@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "kernels.hpp"
+#include "octree.hpp"
 
 namespace mi355rt {
 
@@ -155,6 +156,26 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     dscene_.nodes = d_nodes; dscene_.tris = d_tris; dscene_.normals = d_normals; dscene_.materials = d_mats;
     dscene_.lights = d_lights; dscene_.textures = d_tex; dscene_.texels = d_texels; dscene_.table = d_table;
     dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri; dscene_.lds_nodes = 0;
+    dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr;
+    if (cfg.flags & MI355RT_FLAG_OCTREE_SEMANTICS) {
+        // the reference's own structure (OctTreeIntersector::with_triangles_per_leaf, OCT:66-81)
+        Octree oct;
+        build_octree(scene.tri_verts.data(), ntri, cfg.triangles_per_leaf, oct);
+        oct_stats_[0] = (uint32_t)oct.nodes.size(); oct_stats_[1] = oct.inner; oct_stats_[2] = oct.leaves;
+        oct_stats_[3] = oct.empty_leaves; oct_stats_[4] = oct.max_depth; oct_stats_[5] = (uint32_t)oct.leaf_tris.size();
+        std::vector<BvhTri> prim_tris(std::max(ntri, 1u));
+        std::memset(prim_tris.data(), 0, prim_tris.size() * sizeof(BvhTri));
+        for (uint32_t t = 0; t < ntri; ++t) {
+            const float* v = &scene.tri_verts[9 * (size_t)t];
+            for (int a = 0; a < 3; ++a) { prim_tris[t].v0[a] = v[a]; prim_tris[t].e1[a] = v[3 + a] - v[a]; prim_tris[t].e2[a] = v[6 + a] - v[a]; }
+            prim_tris[t].prim = t; prim_tris[t].geom = scene.tri_geom[t];
+        }
+        void* d_oct = nullptr; uint32_t* d_leaf = nullptr; void* d_ptris = nullptr;
+        if (!upload(d_oct, oct.nodes.data(), oct.nodes.size() * sizeof(OctNodeFlat))) return bail();
+        if (!upload(d_leaf, oct.leaf_tris.data(), oct.leaf_tris.size() * 4)) return bail();
+        if (!upload(d_ptris, prim_tris.data(), prim_tris.size() * sizeof(BvhTri))) return bail();
+        dscene_.oct_nodes = d_oct; dscene_.oct_leaf_tris = d_leaf; dscene_.prim_tris = d_ptris;
+    }
 
     // --- film (film.rs:27-35) and row lists
     const size_t npix = (size_t)cfg.width * cfg.height;
@@ -254,6 +275,7 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     ps.chunk = chunk_; ps.nchunks = (uint32_t)((nsamples + chunk_ - 1) / chunk_); ps.region = chunk_ * records_per_sample_;
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
+    ps.refill_threshold = 8; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
     ps.pull_mode = nsamples >= ((size_t)16 << 20) ? 0u : 2u;
     if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
     const DCamera cam = device_camera();
@@ -273,7 +295,10 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
         }
         const void* in_q = r == 0 ? nullptr : d_queue_[(r - 1) & 1];
         const void* in_c = r == 0 ? nullptr : d_chunk_counts_[(r - 1) & 1];
-        HIP_TRY(launch_trace(stream_, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, d_hits_, d_ctrl_ + r * 16, d_slot_L_, d_film_n_, d_counters_));
+        if (dscene_.oct_nodes)
+            HIP_TRY(launch_trace_octree(stream_, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, d_hits_, d_slot_L_, d_film_n_));
+        else
+            HIP_TRY(launch_trace(stream_, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, d_hits_, d_ctrl_ + r * 16, d_slot_L_, d_film_n_, d_counters_));
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], stream_)); ev_used_ += 2; }
         ++launches_;
         if (r <= cfg.recursions)

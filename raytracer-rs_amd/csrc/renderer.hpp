@@ -39,6 +39,7 @@ public:
     uint32_t current_row = 0;
     uint32_t nodes_per_sample = 1;
     uint32_t level_first[kMaxLevels + 1] = { 0 };
+    uint32_t oct_stats_[8] = { 0 };       // reference-exact mode: nodes, inner, leaves, empty, depth, triangle refs
 
 private:
     Renderer() = default;

@@ -130,4 +130,75 @@ __device__ __forceinline__ void ray_run(const DScene& sc, RayState& s, int* stac
     }
 }
 
+// ---- reference-exact intersector (MI355RT_FLAG_OCTREE_SEMANTICS) ---------------------------------------
+// OctTreeIntersector::intersect_ray / intersect_node, oct_tree_intersector.rs:148-206, 240-272, 348-372,
+// bug for bug: children slab-tested with the precomputed IEEE inverse direction, kept hits sorted by
+// tmin with a STABLE sort, visited front to back, FIRST leaf that yields a hit wins; a leaf yields its
+// closest triangle only if the hit point lies inside the leaf cube (inclusive).  The root cube is never
+// slab-tested.  A slow path by design (<= 70 triangles per leaf): it exists for parity, not for speed.
+__device__ inline void octree_intersect(const DScene& sc, f3 o, f3 d, float& out_t, float& out_u, float& out_v, uint32_t& out_prim)
+{
+    const float4* __restrict__ nodes = (const float4*)sc.oct_nodes;
+    const float4* __restrict__ ptris = (const float4*)sc.prim_tris;
+    const f3 inv = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));     // OCT:241-244
+    out_prim = 0xFFFFFFFFu; out_t = 0.0f; out_u = 0.0f; out_v = 0.0f;
+    int stack[80];                                   // depth <= 9 levels x 8 children
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const int node = stack[--sp];
+        const float4 n0 = nodes[3 * node], n1 = nodes[3 * node + 1], n2 = nodes[3 * node + 2];
+        const int first_child = __float_as_int(n0.w);
+        if (first_child < 0) {
+            // intersect_leaf_triangles, OCT:249-272: strict `<` keeps the first of equal t
+            const uint32_t tri_first = __float_as_uint(n1.w), tri_count = __float_as_uint(n2.x);
+            bool have = false; float bt = 0.0f, bu = 0.0f, bv = 0.0f; uint32_t bp = 0u;
+            for (uint32_t k = 0; k < tri_count; ++k) {
+                const uint32_t prim = sc.oct_leaf_tris[tri_first + k];
+                const float4 t0 = ptris[3 * prim], t1 = ptris[3 * prim + 1], t2 = ptris[3 * prim + 2];
+                const f3 v0 = mk3(t0.x, t0.y, t0.z), v0v1 = mk3(t1.x, t1.y, t1.z), v0v2 = mk3(t2.x, t2.y, t2.z);
+                const f3 pvec = cross3(d, v0v2);
+                const float det = dot3(v0v1, pvec);
+                if (fabsf(det) < 1.1920929e-7f) continue;
+                const float inv_det = div_rn(1.0f, det);
+                const f3 tvec = sub3(o, v0);
+                const float u = dot3(tvec, pvec) * inv_det;
+                const f3 qvec = cross3(tvec, v0v1);
+                const float v = dot3(d, qvec) * inv_det;
+                const float t = dot3(v0v2, qvec) * inv_det;
+                if (u < 0.0f || u > 1.0f) continue;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                if (t < 0.0f) continue;
+                if (!have || t < bt) { have = true; bt = t; bu = u; bv = v; bp = prim; }
+            }
+            if (have) {
+                const f3 hp = add3(o, vscale(d, bt));                          // OCT:164
+                const bool inside = !(hp.x < n0.x || hp.x > n1.x || hp.y < n0.y || hp.y > n1.y || hp.z < n0.z || hp.z > n1.z);   // OCT:34-45
+                if (inside) { out_t = bt; out_u = bu; out_v = bv; out_prim = bp; return; }
+            }
+            continue;
+        }
+        int idx[8]; float dist[8]; int n = 0;
+        for (int i = 0; i < 8; ++i) {
+            const int c = first_child + i;
+            const float4 c0 = nodes[3 * c], c1 = nodes[3 * c + 1];
+            // intersect_cube_inverse_ray, OCT:348-372 (fminf/fmaxf ignore a NaN operand like f32::min/max)
+            const float tx1 = (c0.x - o.x) * inv.x, tx2 = (c1.x - o.x) * inv.x;
+            float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
+            const float ty1 = (c0.y - o.y) * inv.y, ty2 = (c1.y - o.y) * inv.y;
+            tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+            const float tz1 = (c0.z - o.z) * inv.z, tz2 = (c1.z - o.z) * inv.z;
+            tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+            if (tmax >= tmin && tmax > 0.0f) {
+                // stable insertion by tmin ascending (OCT:183); a NaN distance compares as "not less"
+                int j = n - 1;
+                while (j >= 0 && tmin < dist[j]) { idx[j + 1] = idx[j]; dist[j + 1] = dist[j]; --j; }
+                idx[j + 1] = c; dist[j + 1] = tmin;
+                ++n;
+            }
+        }
+        for (int i = n - 1; i >= 0; --i) stack[sp++] = idx[i];                 // nearest child is popped first
+    }
+}
+
 }  // namespace mi355rt

@@ -12,7 +12,8 @@ def bits(a):
 
 
 def make(pkg, scenes, name, w, h, **kw):
-    return pkg.create_raytracer_from_arrays(scenes(name), pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, **kw)
+    tpl = kw.pop("triangles_per_leaf", pkg.DEFAULT_TRIANGLES_PER_LEAF)
+    return pkg.create_raytracer_from_arrays(scenes(name), tpl, w, h, **kw)
 
 
 def test_device_arithmetic_is_ieee(pkg, scenes, oracle):
@@ -308,3 +309,38 @@ def test_full_size_matches_oracle_on_sampled_rows(pkg, scenes, oracle):
     m = on > 0
     assert m.sum() == 3 * w
     assert np.array_equal(bits(s[m]), bits(os_[m]))
+
+
+# ---- reference-exact octree intersector (MI355RT_FLAG_OCTREE_SEMANTICS) ------------------------------------
+@pytest.mark.parametrize("name", ["4boxes", "ico2", "thai2", "ico3_tex"])
+def test_octree_mode_matches_reference_default_semantics(pkg, scenes, oracle, name):
+    """With the octree flag the device intersects with the reference's own octree, bug for bug: hit
+    records, film and pixels are bit-identical to the oracle in its default (octree) mode — including
+    4boxes, where the leaf-cube rule drops hits the true closest-hit search keeps."""
+    g = np.load(os.path.join(GOLDEN, "render_%s.npz" % name))
+    rt = make(pkg, scenes, name, 64, 64, seed=1, flags=pkg.FLAG_OCTREE_SEMANTICS)
+    st = rt.octree_stats()
+    assert [st["nodes"], st["inner"], st["leaves"], st["empty"], st["depth"], st["tri_refs"]] == [int(x) for x in g["octree_stats"]]
+    tuv, prim = rt.intersect_rays(g["rays"])
+    assert np.array_equal(prim, g["octree_prim"])
+    m = prim != 0xFFFFFFFF
+    assert np.array_equal(bits(tuv[m]), bits(g["octree_tuv"][m]))
+    c = rt.render(4)
+    s, q, n = rt.film.pixel_datas()
+    assert [c.primary, c.bounce, c.shadow, c.primary_hits] == [int(x) for x in g["octree_counts"]]
+    assert np.array_equal(bits(s), bits(g["octree_sum"])) and np.array_equal(bits(q), bits(g["octree_sumsq"]))
+    assert np.array_equal(rt.get_tonemapped_pixels(), g["octree_ldr"])
+
+
+def test_octree_mode_other_leaf_sizes_and_frames(pkg, scenes, oracle):
+    """--max_triangles (tris per leaf) reaches the octree build; 50-row frames work in this mode too."""
+    name, w, h = "ico2", 72, 60
+    for tpl in (5, 20, 100):
+        rt = make(pkg, scenes, name, w, h, seed=2, flags=pkg.FLAG_OCTREE_SEMANTICS, triangles_per_leaf=tpl)
+        orc = oracle.Oracle(scenes(name), w, h, tris_per_leaf=tpl, seed=2)
+        so = orc.octree_stats(); sg = rt.octree_stats()
+        assert (sg["nodes"], sg["leaves"], sg["depth"], sg["tri_refs"]) == (so["nodes"], so["leaves"], so["depth"], so["tri_refs"])
+        for _ in range(2):
+            assert rt.trace_frame_additive() == orc.trace_frame_additive()
+        assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0]))
+        assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
