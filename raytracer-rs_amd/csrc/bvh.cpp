@@ -110,6 +110,28 @@ struct Builder {
 
 int32_t leaf_code(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
+// float -> binary16 bit pattern, rounded toward -inf (up == false) or +inf (up == true)
+uint32_t half_bits_directed(float x, bool up)
+{
+    if (x != x) return up ? 0x7C00u : 0xFC00u;                 // NaN: widest possible bound
+    _Float16 h = (_Float16)x;                                   // round to nearest
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    const float back = (float)h;
+    if (up ? back < x : back > x) {
+        // step one representable value in the wanted direction
+        if ((b & 0x7FFFu) == 0) b = up ? 0x0001u : 0x8001u;    // +-0 -> smallest denormal of the right sign
+        else if (((b & 0x8000u) == 0) == up) b += 1;           // moving away from zero
+        else b -= 1;                                           // moving toward zero
+    }
+    return b;
+}
+void pack_box(const Box& box, float pad, uint32_t out[3])
+{
+    for (int a = 0; a < 3; ++a)
+        out[a] = half_bits_directed(box.mn[a] - pad, false) | (half_bits_directed(box.mx[a] + pad, true) << 16);
+}
+
 }  // namespace
 
 void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out)
@@ -125,6 +147,8 @@ void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, 
         out.tris.push_back(t);
         out.root = leaf_code(0, 1);
         out.leaves = 1; out.max_leaf = 1;
+        out.nodes.resize(1);
+        std::memset(out.nodes.data(), 0, sizeof(BvhNode));
         return;
     }
     Builder b;
@@ -171,19 +195,22 @@ void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, 
         out.leaves++; out.max_leaf = std::max(out.max_leaf, n.count); out.max_depth = std::max(out.max_depth, n.depth);
         return leaf_code(first, n.count);
     };
-    if (bfs.empty()) { out.root = emit_leaf(b.tmp[root]); return; }
+    if (bfs.empty()) {
+        out.root = emit_leaf(b.tmp[root]);
+        out.nodes.resize(1);                      // never visited: keeps predicated node fetches in bounds
+        std::memset(out.nodes.data(), 0, sizeof(BvhNode));
+        return;
+    }
     out.nodes.resize(bfs.size());
     for (size_t i = 0; i < bfs.size(); ++i) {
         const TmpNode& n = b.tmp[bfs[i]];
         const TmpNode& c0 = b.tmp[n.left];
         const TmpNode& c1 = b.tmp[n.right];
         BvhNode& o = out.nodes[i];
-        o.q0[0] = c0.box.mn[0] - pad; o.q0[1] = c0.box.mx[0] + pad; o.q0[2] = c0.box.mn[1] - pad; o.q0[3] = c0.box.mx[1] + pad;
-        o.q1[0] = c1.box.mn[0] - pad; o.q1[1] = c1.box.mx[0] + pad; o.q1[2] = c1.box.mn[1] - pad; o.q1[3] = c1.box.mx[1] + pad;
-        o.q2[0] = c0.box.mn[2] - pad; o.q2[1] = c0.box.mx[2] + pad; o.q2[2] = c1.box.mn[2] - pad; o.q2[3] = c1.box.mx[2] + pad;
-        o.child[0] = c0.left >= 0 ? inner_index[n.left] : emit_leaf(c0);
-        o.child[1] = c1.left >= 0 ? inner_index[n.right] : emit_leaf(c1);
-        o.child[2] = o.child[3] = 0;
+        pack_box(c0.box, pad, o.h0);
+        pack_box(c1.box, pad, o.h1);
+        o.child0 = c0.left >= 0 ? inner_index[n.left] : emit_leaf(c0);
+        o.child1 = c1.left >= 0 ? inner_index[n.right] : emit_leaf(c1);
     }
     out.root = 0;
 }

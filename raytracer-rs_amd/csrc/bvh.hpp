@@ -10,13 +10,15 @@
 
 namespace mi355rt {
 
-// 64-byte node holding BOTH child boxes (one fetch decides both children).
-//   q0 = (c0.min.x, c0.max.x, c0.min.y, c0.max.y)
-//   q1 = (c1.min.x, c1.max.x, c1.min.y, c1.max.y)
-//   q2 = (c0.min.z, c0.max.z, c1.min.z, c1.max.z)
-//   q3 = (child0, child1, 0, 0) as int32: >= 0 inner node index, < 0 leaf: ~v = first<<3 | count-1
-struct alignas(16) BvhNode { float q0[4], q1[4], q2[4]; int32_t child[4]; };
-static_assert(sizeof(BvhNode) == 64, "node must be 64 bytes");
+// 32-byte node holding BOTH child boxes as IEEE half floats (one 2 x 16 B fetch decides both children).
+//   h[c] = { min.x | max.x << 16, min.y | max.y << 16, min.z | max.z << 16 } of child c (binary16 bit patterns),
+//   child[c] as int32: >= 0 inner node index, < 0 leaf: ~v = first<<3 | count-1
+// The boxes only steer the search (the exact f32 triangle test decides every hit), so they may be
+// coarse as long as they are conservative: minima are rounded DOWN and maxima UP to half precision
+// (after the padding), coordinates beyond the half range become +-inf.  Halving the node halves the
+// number of divergent 16-byte fetches per step, which is what bounds the trace kernel.
+struct alignas(16) BvhNode { uint32_t h0[3]; int32_t child0; uint32_t h1[3]; int32_t child1; };
+static_assert(sizeof(BvhNode) == 32, "node must be 32 bytes");
 
 // 48-byte triangle in leaf order: v0 + the two edges the reference computes per test
 // (intersect.rs:65-66: v0v1 = v1 - v0, v0v2 = v2 - v0 — same f32 subtractions, done once).

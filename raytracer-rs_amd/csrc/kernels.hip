@@ -40,17 +40,35 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 // sparingly (pull_chunk).
 __device__ __forceinline__ uint32_t global_wave_id() { return blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); }
 
-// Pull the next chunk for this wave (wave-uniform).  mode 0: one atomic on the shared cursor per
-// pull (dynamic balancing; the cursor word sustains ~88 pulls/us, far above the demand of a few
-// thousand chunks per millisecond).  mode 2: static striding, no atomics (wave w takes chunks
-// w, w + nwaves, ...).  Measured on thai2 1080p: dynamic wins for passes >= 16M samples, static for
-// smaller ones (profiles/r01_notes.md).  A relaxed agent-scope load of the cursor in front of the
-// atomic (to skip the end-of-kernel storm) made the kernel 2.5x slower and was dropped.
+// Pull the next chunk for this wave (wave-uniform).
+//   mode 2 (default): static striding, no atomics — wave w takes chunks w, w + nwaves, ...; a wave's
+//     chunks lie about one image height apart, which decorrelates their cost.
+//   mode 0: one atomic on a shared cursor per pull.  One device word sustains only ~88 atomics/us:
+//     131 072 chunks per launch put a 1.5 ms floor under every trace launch (4boxes: 6.4 ms -> 1.4 ms
+//     per 16 spp when the atomics went away).
+//   mode 3: first 3/4 of the chunks static, last quarter dynamic (same speed as mode 2 on thai2).
+// A relaxed agent-scope load of the cursor in front of the atomic (to skip the end-of-kernel storm)
+// made the kernel 2.5x slower and was dropped (profiles/r01_notes.md).
 __device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, bool& first, uint32_t& chunk)
 {
     if (mode == 2u) {
         if (first) { first = false; chunk = global_wave_id(); }
         else chunk += gridDim.x * kWavesPerBlock;
+        return chunk < nchunks;
+    }
+    if (mode == 3u) {
+        // hybrid: the first 3/4 of the chunks are dealt statically (stride = number of waves), the last
+        // quarter dynamically from the cursor, so that one word does not have to serve every pull
+        const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+        const uint32_t nstatic = (nchunks / 4u * 3u) / nwaves * nwaves;
+        const uint32_t next = first ? global_wave_id() : chunk + nwaves;
+        first = false;
+        if (chunk < nstatic || next < nstatic) {          // still in the static part (chunk == previous one)
+            if (next < nstatic) { chunk = next; return true; }
+        }
+        uint32_t v = 0u;
+        if (lane_id() == 0) v = atomicAdd(cursor, 1u);
+        chunk = nstatic + bcast_first(v);
         return chunk < nchunks;
     }
     uint32_t v = 0u;
@@ -189,23 +207,26 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
 
         // ---- while-while scheduling: inner-node steps run for the lanes at inner nodes; lanes that
         // reached a leaf wait until enough of them are there (or nobody is left at an inner node),
-        // so that the expensive triangle code always runs with a well-filled wave.
-        const unsigned long long m_inner = __ballot(busy && rs.node >= 0);
-        bool fin = false;
-        if (m_inner != 0ull) {
-            if (busy && rs.node >= 0) fin = inner_step<COUNT>(sc, rs, stack, kBlock, acc_nodes);
-        }
-        const unsigned long long m_leaf = __ballot(busy && !fin && rs.node < 0);
-        if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(busy && !fin && rs.node >= 0) == 0ull)) {
-            if (busy && !fin && rs.node < 0) fin = leaf_step<COUNT>(sc, rs, stack, kBlock, acc_tris);
-        }
-        if (fin) {
-            busy = false;
-            if (!rs.shadow) {
-                hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
-            } else if (rs.occ != 1) {                                  // not blocked, mod.rs:232
-                float* dst = slot_L + rec;
-                dst[0] = sh_L.x; dst[1] = sh_L.y; dst[2] = sh_L.z;
+        // so that the expensive triangle code always runs with a well-filled wave.  The two sections
+        // are entered on wave-uniform conditions; inside, lanes are predicated, not branched.
+        bool need_pop = false, fin = false;
+        const bool at_inner = busy & (rs.node >= 0);
+        const unsigned long long m_inner = __ballot(at_inner);
+        if (m_inner != 0ull) inner_pred<COUNT>(sc, rs, at_inner, stack, kBlock, (int)ps.stack_depth, need_pop, acc_nodes);
+        const bool at_leaf = busy & !need_pop & (rs.node < 0);
+        const unsigned long long m_leaf = __ballot(at_leaf);
+        if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(busy & !need_pop & (rs.node >= 0)) == 0ull))
+            leaf_pred<COUNT>(sc, rs, at_leaf, need_pop, fin, acc_tris);
+        pop_pred(rs, need_pop, stack, kBlock, (int)ps.stack_depth, fin);
+        if (__ballot(fin) != 0ull) {
+            if (fin) {
+                busy = false;
+                if (!rs.shadow) {
+                    hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
+                } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
+                    float* dst = slot_L + rec;
+                    dst[0] = sh_L.x; dst[1] = sh_L.y; dst[2] = sh_L.z;
+                }
             }
         }
     }
@@ -504,7 +525,7 @@ hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, u
 }
 
 // ---- launchers --------------------------------------------------------------------------------
-static size_t stack_bytes(uint32_t depth) { return (size_t)(depth ? depth : 1u) * kBlock * sizeof(int); }
+static size_t stack_bytes(uint32_t depth) { return (size_t)((depth ? depth : 1u) + 1u) * kBlock * sizeof(int); }   // + one trash row
 
 template <bool P, bool C>
 static int trace_blocks_per_cu(size_t lds)

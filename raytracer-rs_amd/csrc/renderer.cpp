@@ -275,8 +275,8 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     ps.chunk = chunk_; ps.nchunks = (uint32_t)((nsamples + chunk_ - 1) / chunk_); ps.region = chunk_ * records_per_sample_;
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
-    ps.refill_threshold = 8; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
-    ps.pull_mode = nsamples >= ((size_t)16 << 20) ? 0u : 2u;
+    ps.refill_threshold = 16; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
+    ps.pull_mode = 2u;                  // static striding: no atomics (see pull_chunk)
     if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
     const DCamera cam = device_camera();
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;

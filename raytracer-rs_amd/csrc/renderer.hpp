@@ -72,7 +72,7 @@ private:
     void* d_hits_ = nullptr;             // hit records of the round being processed (16 B per queue record)
     uint32_t chunk_ = 256;               // primary samples per work chunk
     uint32_t max_level_nodes_ = 1;
-    uint32_t leaf_threshold_ = 24;
+    uint32_t leaf_threshold_ = 16;
     float* d_slot_L_ = nullptr;
     size_t pass_capacity_ = 0;           // samples
     size_t queue_records_ = 0;

@@ -36,6 +36,25 @@ __device__ __forceinline__ void ray_init(RayState& s, f3 o, f3 d, bool shadow, i
     s.node = root; s.tri = 0u; s.sp = 0; s.occ = 0; s.shadow = shadow;
 }
 
+// Two child boxes of a 32-byte node (bvh.hpp): half -> float, then the slab test with the
+// approximate reciprocal direction.  Entry / exit distances of both children.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void unpack_bounds(uint32_t w, float& lo, float& hi)
+{
+    const half2_t h = __builtin_bit_cast(half2_t, w);
+    lo = (float)h.x; hi = (float)h.y;
+}
+__device__ __forceinline__ void slab_child(const uint4 q, const RayState& s, float& tn, float& tf)
+{
+    float x0, x1, y0, y1, z0, z1;
+    unpack_bounds(q.x, x0, x1); unpack_bounds(q.y, y0, y1); unpack_bounds(q.z, z0, z1);
+    const float a1 = (x0 - s.o.x) * s.idx, a2 = (x1 - s.o.x) * s.idx;
+    const float b1 = (y0 - s.o.y) * s.idy, b2 = (y1 - s.o.y) * s.idy;
+    const float c1 = (z0 - s.o.z) * s.idz, c2 = (z1 - s.o.z) * s.idz;
+    tn = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
+    tf = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), s.tlimit));
+}
+
 // Pop the next deferred node; returns true when the stack is empty (ray finished).
 __device__ __forceinline__ bool ray_pop(RayState& s, const int* stack, int stride)
 {
@@ -52,22 +71,14 @@ __device__ __forceinline__ bool ray_pop(RayState& s, const int* stack, int strid
 template <bool COUNT>
 __device__ __forceinline__ bool inner_step(const DScene& sc, RayState& s, int* stack, int stride, uint32_t& n_nodes)
 {
-    const float4* __restrict__ nodes = (const float4*)sc.nodes;
+    const uint4* __restrict__ nodes = (const uint4*)sc.nodes;
     if (COUNT) ++n_nodes;
-    const float4 q0 = nodes[4 * s.node], q1 = nodes[4 * s.node + 1], q2 = nodes[4 * s.node + 2];
-    const float4 q3 = nodes[4 * s.node + 3];
-    float a1 = (q0.x - s.o.x) * s.idx, a2 = (q0.y - s.o.x) * s.idx;
-    float b1 = (q0.z - s.o.y) * s.idy, b2 = (q0.w - s.o.y) * s.idy;
-    float c1 = (q2.x - s.o.z) * s.idz, c2 = (q2.y - s.o.z) * s.idz;
-    const float tn0 = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
-    const float tf0 = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), s.tlimit));
-    a1 = (q1.x - s.o.x) * s.idx; a2 = (q1.y - s.o.x) * s.idx;
-    b1 = (q1.z - s.o.y) * s.idy; b2 = (q1.w - s.o.y) * s.idy;
-    c1 = (q2.z - s.o.z) * s.idz; c2 = (q2.w - s.o.z) * s.idz;
-    const float tn1 = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
-    const float tf1 = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), s.tlimit));
+    const uint4 q0 = nodes[2 * s.node], q1 = nodes[2 * s.node + 1];
+    float tn0, tf0, tn1, tf1;
+    slab_child(q0, s, tn0, tf0);
+    slab_child(q1, s, tn1, tf1);
     const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-    const int c0i = __float_as_int(q3.x), c1i = __float_as_int(q3.y);
+    const int c0i = (int)q0.w, c1i = (int)q1.w;
     s.tri = 0u;
     if (h0 && h1) {
         const bool sw = tn1 < tn0;
@@ -128,6 +139,79 @@ __device__ __forceinline__ void ray_run(const DScene& sc, RayState& s, int* stac
         const bool done = s.node >= 0 ? inner_step<COUNT>(sc, s, stack, stride, n_nodes) : leaf_step<COUNT>(sc, s, stack, stride, n_tris);
         if (done) break;
     }
+}
+
+// ---- predicated steps for the persistent trace kernel ------------------------------------------------------
+// Same arithmetic as inner_step / leaf_step, written WITHOUT per-lane branches: every lane of the wave
+// runs the code, `pred` says whether the lane takes part, state changes are selects, LDS pushes of lanes
+// that do not push go to a trash row.  Divergent branches cost this kernel more scalar exec-mask
+// bookkeeping than the arithmetic they skip (profiles/r01_notes.md).
+template <bool COUNT>
+__device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, bool pred, int* stack, int stride, int trash_row,
+                                           bool& need_pop, uint32_t& n_nodes)
+{
+    const uint4* __restrict__ nodes = (const uint4*)sc.nodes;
+    if (COUNT) n_nodes += pred ? 1u : 0u;
+    const int ni = pred ? s.node : 0;
+    const uint4 q0 = nodes[2 * ni], q1 = nodes[2 * ni + 1];
+    float tn0, tf0, tn1, tf1;
+    slab_child(q0, s, tn0, tf0);
+    slab_child(q1, s, tn1, tf1);
+    // bitwise & | on bools throughout: && || would compile to short-circuit branches
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+    const int c0i = (int)q0.w, c1i = (int)q1.w;
+    const bool sw = tn1 < tn0;                       // child 1 is nearer
+    const bool take1 = h1 & (!h0 | sw);
+    const int near_c = take1 ? c1i : c0i, far_c = take1 ? c0i : c1i;
+    const bool push = pred & h0 & h1;
+    stack[(push ? s.sp : trash_row) * stride] = far_c;
+    s.sp += push ? 1 : 0;
+    const bool any = h0 | h1;
+    s.node = (pred & any) ? near_c : s.node;
+    s.tri = pred ? 0u : s.tri;
+    need_pop = need_pop | (pred & !any);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, bool pred, bool& need_pop, bool& fin, uint32_t& n_tris)
+{
+    const float4* __restrict__ tris = (const float4*)sc.tris;
+    const uint32_t code = ~(uint32_t)s.node;
+    const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+    if (COUNT) n_tris += pred ? 1u : 0u;
+    const uint32_t ti = pred ? first + s.tri : 0u;
+    const float4 t0 = tris[3 * ti], t1 = tris[3 * ti + 1], t2 = tris[3 * ti + 2];
+    // Moller-Trumbore "late out", intersect.rs:62-98, same operation order
+    const f3 v0 = mk3(t0.x, t0.y, t0.z), v0v1 = mk3(t1.x, t1.y, t1.z), v0v2 = mk3(t2.x, t2.y, t2.z);
+    const f3 pvec = cross3(s.d, v0v2);
+    const float det = dot3(v0v1, pvec);
+    const float inv_det = div_rn(1.0f, det);
+    const f3 tvec = sub3(s.o, v0);
+    const float u = dot3(tvec, pvec) * inv_det;
+    const f3 qvec = cross3(tvec, v0v1);
+    const float v = dot3(s.d, qvec) * inv_det;
+    const float t = dot3(v0v2, qvec) * inv_det;
+    const bool ok = pred & !(fabsf(det) < 1.1920929e-7f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(t < 0.0f);
+    const uint32_t prim = __float_as_uint(t0.w);
+    const bool better = ok & !s.shadow & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
+    s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
+    const bool sh = ok & s.shadow & (t <= s.tlimit);
+    const bool sh_far = sh & (t > 0.01f), sh_near = sh & !(t > 0.01f);
+    s.tlimit = better ? t : (sh_far ? 0.01f : s.tlimit);
+    s.occ = sh_near ? 2 : (sh_far ? 1 : s.occ);
+    fin = fin | sh_near;
+    s.tri += pred ? 1u : 0u;
+    need_pop = need_pop | (pred & !sh_near & (s.tri >= cnt));
+}
+
+__device__ __forceinline__ void pop_pred(RayState& s, bool need_pop, const int* stack, int stride, int trash_row, bool& fin)
+{
+    const bool take = need_pop & (s.sp > 0);
+    const int popped = stack[(take ? s.sp - 1 : trash_row) * stride];
+    fin = fin | (need_pop & (s.sp == 0));
+    s.sp -= take ? 1 : 0;
+    s.node = take ? popped : s.node;
+    s.tri = need_pop ? 0u : s.tri;
 }
 
 // ---- reference-exact intersector (MI355RT_FLAG_OCTREE_SEMANTICS) ---------------------------------------
