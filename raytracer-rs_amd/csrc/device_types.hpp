@@ -71,6 +71,7 @@ struct DPass {
 
 struct DCounters {            // one set per render call, zeroed at its start
     unsigned long long bounce, shadow, primary_hits, nodes_visited, tris_tested;
+    unsigned long long inner_execs, leaf_execs;   // COUNT mode: wave-level executions of the inner / leaf section
     unsigned int overflow;
     unsigned int pad;
 };

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
 {
     extern __shared__ int s_stack[];                 // ps.stack_depth rows of kBlock ints
     int* stack = &s_stack[threadIdx.x];
-    uint32_t acc_nodes = 0, acc_tris = 0;
+    uint32_t acc_nodes = 0, acc_tris = 0, acc_ie = 0, acc_le = 0;
 
     // wave-uniform work state: the chunk being handed out
     uint32_t w_chunk = 0u, w_next = 0u, w_nrad = 0u, w_ntot = 0u;
@@ -212,11 +212,11 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
         bool need_pop = false, fin = false;
         const bool at_inner = busy & (rs.node >= 0);
         const unsigned long long m_inner = __ballot(at_inner);
-        if (m_inner != 0ull) inner_pred<COUNT>(sc, rs, at_inner, stack, kBlock, (int)ps.stack_depth, need_pop, acc_nodes);
+        if (m_inner != 0ull) { inner_pred<COUNT>(sc, rs, at_inner, stack, kBlock, (int)ps.stack_depth, need_pop, acc_nodes); if (COUNT) ++acc_ie; }
         const bool at_leaf = busy & !need_pop & (rs.node < 0);
         const unsigned long long m_leaf = __ballot(at_leaf);
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(busy & !need_pop & (rs.node >= 0)) == 0ull))
-            leaf_pred<COUNT>(sc, rs, at_leaf, need_pop, fin, acc_tris);
+            { leaf_pred<COUNT>(sc, rs, at_leaf, need_pop, fin, acc_tris); if (COUNT) ++acc_le; }
         pop_pred(rs, need_pop, stack, kBlock, (int)ps.stack_depth, fin);
         if (__ballot(fin) != 0ull) {
             if (fin) {
@@ -233,7 +233,10 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { acc_nodes += __shfl_down((int)acc_nodes, off, 64); acc_tris += __shfl_down((int)acc_tris, off, 64); }
         DCounters* cs = &counters[global_wave_id() % kShards];
-        if (lane_id() == 0) { atomicAdd(&cs->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&cs->tris_tested, (unsigned long long)acc_tris); }
+        if (lane_id() == 0) {
+            atomicAdd(&cs->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&cs->tris_tested, (unsigned long long)acc_tris);
+            atomicAdd(&cs->inner_execs, (unsigned long long)acc_ie); atomicAdd(&cs->leaf_execs, (unsigned long long)acc_le);
+        }
     }
 }
 

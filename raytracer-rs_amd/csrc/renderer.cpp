@@ -1,6 +1,7 @@
 // renderer.cpp — see renderer.hpp.
 #include "renderer.hpp"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "kernels.hpp"
@@ -326,10 +327,12 @@ bool Renderer::end_call(uint64_t primary)
     for (const DCounters& s : shard) {
         c.bounce += s.bounce; c.shadow += s.shadow; c.primary_hits += s.primary_hits;
         c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
+        c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs;
     }
     counts = mi355rt_ray_counts{};
     counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
     counts.nodes_visited = c.nodes_visited; counts.tris_tested = c.tris_tested; counts.trace_launches = launches_;
+    if (getenv("MI355RT_DEBUG_UTIL")) fprintf(stderr, "[mi355rt] inner execs %llu (lane util %.3f) leaf execs %llu (lane util %.3f)\n", c.inner_execs, c.inner_execs ? (double)c.nodes_visited / (64.0 * c.inner_execs) : 0.0, c.leaf_execs, c.leaf_execs ? (double)c.tris_tested / (64.0 * c.leaf_execs) : 0.0);
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
     counts.total_ms = ms;
