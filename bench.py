@@ -17,8 +17,9 @@ all_gather of the packed u32 stripes per frame.
 
 Rank 0 prints ONE JSON line (see the repo instructions for the contract).  Extra objects:
   roofline      dominant kernel = trace_kernel (closest-hit traversal).  achieved = algorithmic bytes
-                (64 B x nodes visited + 48 B x triangles tested + 96 B per ray, the
-                step counts measured live by the instrumented kernel variant) / summed HIP-event time of
+                (node bytes x nodes visited + 48 B x triangles tested + 96 B per ray; this
+                build's node is 32 B, not the 64 B the survey assumed; step counts measured live by the
+                instrumented kernel variant) / summed HIP-event time of
                 the trace launches of the timed frames.  peak = 8000 GB/s (HBM3E spec).  The scene is
                 cache-resident, so this is a LOGICAL rate, not HBM traffic.
   cpu_baseline  the CPU oracle (C restatement of the reference: octree, recursive radiance) timed on this
@@ -125,7 +126,9 @@ def main():
     total_rays = primary + bounce + shadow
 
     if rank == 0:
-        bytes_per_ray = 64.0 * nodes_per_ray + 48.0 * tris_per_ray + 96.0
+        acc = rt.accel_stats()
+        node_bytes = acc["node_bytes"] / max(acc["nodes"], 1)        # 32 B: both child boxes in half precision (SURVEY assumed 64 B)
+        bytes_per_ray = node_bytes * nodes_per_ray + 48.0 * tris_per_ray + 96.0
         # trace_ms is summed over ranks and total_rays too: the ratio is the per-GPU logical rate
         achieved = total_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         out = {
@@ -145,7 +148,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "trace_kernel", "launches": int(launches), "avg_launch_ms": round(trace_ms / max(launches, 1), 4),
-                         "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                         "bytes_per_ray": round(bytes_per_ray, 1), "node_bytes": node_bytes, "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
                          "note": "logical bytes (SURVEY.md 8d); the 1.5 MB scene is cache-resident, measured HBM traffic is queues + film only"},
         }
         if not args.no_cpu_baseline and world == 1:

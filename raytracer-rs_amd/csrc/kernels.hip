@@ -24,6 +24,7 @@
 // tests are free-form: boxes are padded (bvh.cpp) and the test is conservative.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "device_math.hpp"
 #include "device_types.hpp"
 #include "kernels.hpp"
@@ -553,7 +554,9 @@ hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool coun
     const size_t lds = stack_bytes(ps.stack_depth);
     const int per_cu = primary ? (count ? trace_blocks_per_cu<true, true>(lds) : trace_blocks_per_cu<true, false>(lds))
                                : (count ? trace_blocks_per_cu<false, true>(lds) : trace_blocks_per_cu<false, false>(lds));
-    dim3 grid((unsigned)(num_cus * per_cu)), block(kBlock);
+    int use_per_cu = per_cu;
+    if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= per_cu) use_per_cu = v; }   // occupancy experiment
+    dim3 grid((unsigned)(num_cus * use_per_cu)), block(kBlock);
     const float4* iq = (const float4*)in_q; const uint2* ic = (const uint2*)in_counts; float4* hq = (float4*)hits;
     if (primary) {
         if (count) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);

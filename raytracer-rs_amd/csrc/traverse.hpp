@@ -16,7 +16,9 @@ namespace mi355rt {
 
 struct RayState {
     f3 o, d;
-    float idx, idy, idz;   // 1/d (approximate reciprocal: only the padded box tests use it)
+    float idx, idy, idz;   // 1/d' (approximate reciprocal; d' = d with tiny components pushed away from 0: box tests only)
+    float oidx, oidy, oidz; // -o/d'
+    uint32_t selx, sely, selz; // v_perm selectors: identity, or swap the two halves when d' < 0
     float tlimit;          // only hits with t <= tlimit can still change the result
     float t, u, v;
     uint32_t prim;         // 0xFFFFFFFF = no hit yet
@@ -30,29 +32,44 @@ struct RayState {
 __device__ __forceinline__ void ray_init(RayState& s, f3 o, f3 d, bool shadow, int root)
 {
     s.o = o; s.d = d;
-    s.idx = __builtin_amdgcn_rcpf(d.x); s.idy = __builtin_amdgcn_rcpf(d.y); s.idz = __builtin_amdgcn_rcpf(d.z);
+    // direction used by the BOX tests only: components below 1e-12 of the largest one are pushed to
+    // +-1e-12 of it (the ray tilts by < 1e-12 of its length, far inside the box padding), so that 1/d is
+    // finite.  A null direction gives 1/d = 0: every box passes, no triangle can be hit (det = 0).
+    const float dmax = fmaxf(fabsf(d.x), fmaxf(fabsf(d.y), fabsf(d.z)));
+    const float deps = dmax * 1e-12f;
+    const float bx = fabsf(d.x) < deps ? __builtin_copysignf(deps, d.x) : d.x;
+    const float by = fabsf(d.y) < deps ? __builtin_copysignf(deps, d.y) : d.y;
+    const float bz = fabsf(d.z) < deps ? __builtin_copysignf(deps, d.z) : d.z;
+    const bool null_dir = !(dmax > 0.0f);
+    s.idx = null_dir ? 0.0f : __builtin_amdgcn_rcpf(bx); s.idy = null_dir ? 0.0f : __builtin_amdgcn_rcpf(by); s.idz = null_dir ? 0.0f : __builtin_amdgcn_rcpf(bz);
+    s.oidx = -(o.x * s.idx); s.oidy = -(o.y * s.idy); s.oidz = -(o.z * s.idz);
+    s.selx = __builtin_signbitf(bx) ? 0x01000302u : 0x03020100u;
+    s.sely = __builtin_signbitf(by) ? 0x01000302u : 0x03020100u;
+    s.selz = __builtin_signbitf(bz) ? 0x01000302u : 0x03020100u;
     s.tlimit = shadow ? 0x1.fffffep-1f : __builtin_inff();     // shadow: t < 1.0
     s.t = __builtin_inff(); s.u = 0.0f; s.v = 0.0f; s.prim = 0xFFFFFFFFu;
     s.node = root; s.tri = 0u; s.sp = 0; s.occ = 0; s.shadow = shadow;
 }
 
-// Two child boxes of a 32-byte node (bvh.hpp): half -> float, then the slab test with the
-// approximate reciprocal direction.  Entry / exit distances of both children.
+// Slab test of one child box of a 32-byte node (bvh.hpp).  Per axis the two half-precision bounds sit
+// in one 32-bit word (min | max << 16).  A per-ray byte-permute selector swaps the halves when the
+// direction component is negative, so the low half is always the NEAR plane and the high half the FAR
+// plane: no per-axis min/max.  Each plane distance is one mixed-precision fma (v_fma_mix_f32 reads the
+// half directly): t = b * (1/d) + (-o/d).  This is not the reference's (b - o) * inv and need not be:
+// boxes only steer the search; they are padded by 2e-5 of the scene diagonal and rounded outward, far
+// above the rounding difference (direction components are kept away from zero in ray_init, so 1/d is
+// finite and the fma form cannot produce inf - inf).
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void unpack_bounds(uint32_t w, float& lo, float& hi)
-{
-    const half2_t h = __builtin_bit_cast(half2_t, w);
-    lo = (float)h.x; hi = (float)h.y;
-}
 __device__ __forceinline__ void slab_child(const uint4 q, const RayState& s, float& tn, float& tf)
 {
-    float x0, x1, y0, y1, z0, z1;
-    unpack_bounds(q.x, x0, x1); unpack_bounds(q.y, y0, y1); unpack_bounds(q.z, z0, z1);
-    const float a1 = (x0 - s.o.x) * s.idx, a2 = (x1 - s.o.x) * s.idx;
-    const float b1 = (y0 - s.o.y) * s.idy, b2 = (y1 - s.o.y) * s.idy;
-    const float c1 = (z0 - s.o.z) * s.idz, c2 = (z1 - s.o.z) * s.idz;
-    tn = fmaxf(fmaxf(fminf(a1, a2), fminf(b1, b2)), fmaxf(fminf(c1, c2), 0.0f));
-    tf = fminf(fminf(fmaxf(a1, a2), fmaxf(b1, b2)), fminf(fmaxf(c1, c2), s.tlimit));
+    const half2_t hx = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(q.x, q.x, s.selx));
+    const half2_t hy = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(q.y, q.y, s.sely));
+    const half2_t hz = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(q.z, q.z, s.selz));
+    const float nx = __builtin_fmaf((float)hx.x, s.idx, s.oidx), fx = __builtin_fmaf((float)hx.y, s.idx, s.oidx);
+    const float ny = __builtin_fmaf((float)hy.x, s.idy, s.oidy), fy = __builtin_fmaf((float)hy.y, s.idy, s.oidy);
+    const float nz = __builtin_fmaf((float)hz.x, s.idz, s.oidz), fz = __builtin_fmaf((float)hz.y, s.idz, s.oidz);
+    tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    tf = fminf(fminf(fx, fy), fminf(fz, s.tlimit));
 }
 
 // Pop the next deferred node; returns true when the stack is empty (ray finished).
