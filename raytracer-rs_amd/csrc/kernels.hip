@@ -285,6 +285,7 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(DScene sc, DCamera cam, D
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       const float4* __restrict__ hits,
                                                       float4* __restrict__ out_q, uint2* __restrict__ out_counts,
+                                                      float* __restrict__ slot_L, uint32_t* __restrict__ sample_slot,
                                                       const uint32_t* __restrict__ film_n, DCounters* counters)
 {
     extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.list_cap hit indices
@@ -304,6 +305,16 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(DScene sc, DCamera cam, D
             uint32_t n_new;
             const uint32_t pos = wave_append(valid, cnt, n_new);
             if (valid) list[pos] = i;
+            // primary round: light-term slots are handed out per chunk to the samples that hit something
+            // (74 % of the primary samples miss and need neither a slot nor zero-filling)
+            if (PRIMARY && i < n_rad) sample_slot[chunk * ps.chunk + i] = valid ? chunk * ps.chunk + pos : kMiss;
+        }
+        if (PRIMARY) {
+            // zero the slots this chunk uses: a node whose shadow ray is blocked, or that is never
+            // reached, must read back as black (mod.rs:99-100, 170)
+            const uint32_t per = ps.nodes_per_sample * sc.nlights * 3u;
+            float* z = slot_L + (size_t)chunk * ps.chunk * per;
+            for (uint32_t k = (uint32_t)lane; k < cnt * per; k += 64u) z[k] = 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t out_front = 0u, out_back = 0u;
@@ -316,8 +327,8 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(DScene sc, DCamera cam, D
                 const uint32_t i = list[j + (uint32_t)lane];
                 h = hits[base + i];
                 if (PRIMARY) {
-                    slot = chunk * ps.chunk + i;
-                    primary_sample(cam, ps, film_n, slot, pixel, sampleno, o, d);
+                    slot = chunk * ps.chunk + j + (uint32_t)lane;       // == sample_slot[chunk * ps.chunk + i]
+                    primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
                 } else {
                     const float4 r0 = in_q[3 * (base + i)], r1 = in_q[3 * (base + i) + 1], r2 = in_q[3 * (base + i) + 2];
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
@@ -427,6 +438,7 @@ __device__ f3 node_radiance(const float* __restrict__ L, const DPass& ps, uint32
 }
 
 __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, uint32_t nlights, const float* __restrict__ slot_L,
+                                                     const uint32_t* __restrict__ sample_slot,
                                                      float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,9 +453,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
         n = film_n[pixel];
     }
     for (uint32_t s = 0; s < spp; ++s) {
-        const float* L = slot_L + 3ull * ((size_t)(s * ps.npix + p) * ps.nodes_per_sample * nlights);
-        f3 c;
-        switch (ps.recursions) {
+        const uint32_t sl = sample_slot[s * ps.npix + p];
+        const float* L = slot_L + 3ull * ((size_t)sl * ps.nodes_per_sample * nlights);
+        f3 c = mk3(0.0f, 0.0f, 0.0f);                                   // primary miss: RGB::black(), mod.rs:100
+        if (sl != 0xFFFFFFFFu) switch (ps.recursions) {
             case 0: c = node_radiance<0>(L, ps, nlights, 0, 0); break;
             case 1: c = node_radiance<1>(L, ps, nlights, 0, 0); break;
             case 2: c = node_radiance<2>(L, ps, nlights, 0, 0); break;
@@ -583,7 +596,7 @@ hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, co
 
 hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
                         const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts,
-                        const uint32_t* film_n, DCounters* counters)
+                        float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters)
 {
     const size_t lds = (size_t)ps.list_cap * kWavesPerBlock * sizeof(uint32_t);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -592,17 +605,17 @@ hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DSc
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(kBlock);
     if (primary) hipLaunchKernelGGL((shade_kernel<true>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
-                                    (const float4*)hits, (float4*)out_q, (uint2*)out_counts, film_n, counters);
+                                    (const float4*)hits, (float4*)out_q, (uint2*)out_counts, slot_L, sample_slot, film_n, counters);
     else hipLaunchKernelGGL((shade_kernel<false>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
-                            (const float4*)hits, (float4*)out_q, (uint2*)out_counts, film_n, counters);
+                            (const float4*)hits, (float4*)out_q, (uint2*)out_counts, slot_L, sample_slot, film_n, counters);
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L,
+hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
 {
     dim3 block(256), grid((ps.npix + 255) / 256);
-    hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, ps, width, nlights, slot_L, film_sum, film_sumsq, film_n, debug_color);
+    hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, ps, width, nlights, slot_L, sample_slot, film_sum, film_sumsq, film_n, debug_color);
     return hipGetLastError();
 }
 

@@ -13,8 +13,8 @@ hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, co
                                const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n);
 hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
                         const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts,
-                        const uint32_t* film_n, DCounters* counters);
-hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L,
+                        float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters);
+hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color);
 hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t nrows, uint32_t width, bool packed,
                           const float* film_sum, const uint32_t* film_n, uint32_t* out);

@@ -218,6 +218,7 @@ Renderer::~Renderer()
     if (d_queue_[0]) (void)hipFree(d_queue_[0]);
     if (d_queue_[1]) (void)hipFree(d_queue_[1]);
     if (d_slot_L_) (void)hipFree(d_slot_L_);
+    if (d_sample_slot_) (void)hipFree(d_sample_slot_);
     for (int i = 0; i < 2; ++i) if (d_chunk_counts_[i]) (void)hipFree(d_chunk_counts_[i]);
     if (d_hits_) (void)hipFree(d_hits_);
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
@@ -254,7 +255,9 @@ bool Renderer::ensure_pass_capacity(size_t nsamples)
     }
     if (d_hits_) { (void)hipFree(d_hits_); d_hits_ = nullptr; }
     HIP_TRY(hipMalloc(&d_hits_, records * 16));
-    HIP_TRY(hipMalloc((void**)&d_slot_L_, nsamples * nodes_per_sample * std::max(nlights_, 1u) * 12));
+    HIP_TRY(hipMalloc((void**)&d_slot_L_, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
+    if (d_sample_slot_) { (void)hipFree(d_sample_slot_); d_sample_slot_ = nullptr; }
+    HIP_TRY(hipMalloc((void**)&d_sample_slot_, nchunks * chunk_ * 4));
     pass_capacity_ = nsamples;
     queue_records_ = records;
     return true;
@@ -283,7 +286,6 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
     const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
 
-    HIP_TRY(hipMemsetAsync(d_slot_L_, 0, nsamples * nodes_per_sample * std::max(nlights_, 1u) * 12, stream_));
     HIP_TRY(hipMemsetAsync(d_ctrl_, 0, kMaxRounds * 64, stream_));
     // round r: trace the rays of level r (+ the shadow rays emitted by level r-1), then shade level r
     const uint32_t rounds = cfg.recursions + 2;
@@ -303,9 +305,9 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], stream_)); ev_used_ += 2; }
         ++launches_;
         if (r <= cfg.recursions)
-            HIP_TRY(launch_shade(stream_, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, d_hits_, d_queue_[r & 1], d_chunk_counts_[r & 1], d_film_n_, d_counters_));
+            HIP_TRY(launch_shade(stream_, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, d_hits_, d_queue_[r & 1], d_chunk_counts_[r & 1], d_slot_L_, d_sample_slot_, d_film_n_, d_counters_));
     }
-    HIP_TRY(launch_resolve(stream_, ps, cfg.width, nlights_, d_slot_L_, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
+    HIP_TRY(launch_resolve(stream_, ps, cfg.width, nlights_, d_slot_L_, d_sample_slot_, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
     return true;
 }
 
@@ -488,7 +490,10 @@ bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, fl
     HIP_TRY(hipStreamSynchronize(stream_));
     const uint32_t nl = std::max(nlights_, 1u);
     std::vector<float> raw((size_t)nodes_per_sample * nl * 3);
-    HIP_TRY(hipMemcpy(raw.data(), d_slot_L_, raw.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t sl = 0xFFFFFFFFu;
+    HIP_TRY(hipMemcpy(&sl, d_sample_slot_, 4, hipMemcpyDeviceToHost));
+    if (sl != 0xFFFFFFFFu) HIP_TRY(hipMemcpy(raw.data(), d_slot_L_ + (size_t)sl * raw.size(), raw.size() * 4, hipMemcpyDeviceToHost));
+    else std::fill(raw.begin(), raw.end(), 0.0f);
     HIP_TRY(hipMemcpy(color3, d_debug_color_, 12, hipMemcpyDeviceToHost));
     for (uint32_t nd = 0; nd < nodes_per_sample; ++nd) {
         float acc[3] = { 0.0f, 0.0f, 0.0f };

@@ -74,6 +74,7 @@ private:
     uint32_t max_level_nodes_ = 1;
     uint32_t leaf_threshold_ = 16;
     float* d_slot_L_ = nullptr;
+    uint32_t* d_sample_slot_ = nullptr;  // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
     size_t pass_capacity_ = 0;           // samples
     size_t queue_records_ = 0;
     uint32_t records_per_sample_ = 1;
