@@ -16,6 +16,7 @@ constexpr uint32_t kMaxLevels = kMaxRecursions + 1;
 constexpr uint32_t kRayRecordBytes = 48;
 constexpr uint32_t kShards = 64;            // copies of every contended device word (work cursors, counters)
 constexpr uint32_t kMaxRounds = kMaxRecursions + 2;
+constexpr uint32_t kCullRects = 16;
 
 struct DMaterial { float r, g, b; uint32_t kind_tex; };       // kind_tex: bit 31 = texture, low bits = texture id
 struct DLight { float px, py, pz, cr, cg, cb; };
@@ -44,6 +45,10 @@ struct DCamera {
     float origin[3];          // orientation_matrix * (0,0,0,1)
     float max_x, max_y;
     uint32_t width, height;
+    // screen-space bounds of the (padded) scene box in the camera's (dir_x, dir_y) plane: primary-ray
+    // chunks whose pixel footprint lies outside cannot hit anything and are skipped (cull_valid == 0: off)
+    uint32_t cull_valid;      // number of rectangles below (0: culling off)
+    float cull_rect[kCullRects][4];   // x0, x1, y0, y1 of the top BVH subtrees
 };
 
 struct DPass {

@@ -128,6 +128,38 @@ __device__ __forceinline__ void primary_sample(const DCamera& cam, const DPass& 
     o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
 }
 
+// Frustum culling of a whole chunk of primary samples.  The samples of a chunk are consecutive pixels
+// of (at most two) image rows at one sample index; their (dir_x, dir_y) of camera.rs:81-84 lie in a
+// rectangle whatever the jitter.  If that rectangle misses the screen-space bounds of every one of the
+// (up to 16) top BVH subtree boxes, no ray of the chunk can hit anything: all of them miss (mod.rs:99-100).  Purely
+// conservative: it only ever skips work whose outcome is "miss".
+__device__ __forceinline__ bool chunk_is_culled(const DCamera& cam, const DPass& ps, uint32_t chunk, uint32_t n)
+{
+    if (!cam.cull_valid || ps.use_explicit || n == 0u) return false;
+    const uint32_t g0 = chunk * ps.chunk, g1 = g0 + n - 1u;
+    if (g0 / ps.npix != g1 / ps.npix) return false;                  // straddles two sample indices
+    const uint32_t p0 = g0 % ps.npix, p1 = g1 % ps.npix;
+    const uint32_t r0 = p0 / cam.width, r1 = p1 / cam.width;
+    if (r1 - r0 > 1u) return false;
+    for (uint32_t r = r0; r <= r1; ++r) {
+        const uint32_t xa = r == r0 ? p0 % cam.width : 0u, xb = r == r1 ? p1 % cam.width : cam.width - 1u;
+        const uint32_t row = ps.rows[ps.row0 + r];
+        const uint32_t ia = row * cam.width + xa, ib = row * cam.width + xb;
+        const uint32_t va = (ps.flags & 1u) ? ia / cam.width : ia / cam.height, vb = (ps.flags & 1u) ? ib / cam.width : ib / cam.height;
+        // same expressions as primary_sample with jitter 0 and 1 (monotonic in u, v), widened a little
+        const float x_lo = -cam.max_x + 2.0f * cam.max_x * ((float)xa / (float)cam.width);
+        const float x_hi = -cam.max_x + 2.0f * cam.max_x * (((float)xb + 1.0f) / (float)cam.width);
+        const float y_lo = -cam.max_y + 2.0f * cam.max_y * ((float)va / (float)cam.height);
+        const float y_hi = -cam.max_y + 2.0f * cam.max_y * (((float)vb + 1.0f) / (float)cam.height);
+        const float ex = 1e-5f * cam.max_x, ey = 1e-5f * cam.max_y;
+        for (uint32_t k = 0; k < cam.cull_valid; ++k) {
+            const bool outside = x_hi + ex < cam.cull_rect[k][0] || x_lo - ex > cam.cull_rect[k][1] || y_hi + ey < cam.cull_rect[k][2] || y_lo - ey > cam.cull_rect[k][3];
+            if (!outside) return false;
+        }
+    }
+    return true;
+}
+
 // record index of ray i of a chunk: radiance rays from the front, shadow rays from the back
 __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, uint32_t i, uint32_t n_rad)
 {
@@ -137,7 +169,7 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
 
 // ---- trace: closest hit of every ray of a round --------------------------------------------------
 template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, DPass ps,
+__global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam, DPass ps,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       float4* __restrict__ hits, uint32_t* cursor,
                                                       float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
@@ -171,7 +203,11 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, DCamera cam, D
                 c = w_chunk;
                 if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, w_first, c)) { exhausted = true; break; }
                 w_chunk = c; w_next = 0u;
-                if (PRIMARY) { w_nrad = min(ps.chunk, ps.nsamples - c * ps.chunk); w_ntot = w_nrad; }
+                if (PRIMARY) {
+                    w_nrad = min(ps.chunk, ps.nsamples - c * ps.chunk);
+                    if (chunk_is_culled(cam, ps, c, w_nrad)) w_nrad = 0u;    // the shade kernel makes the same decision
+                    w_ntot = w_nrad;
+                }
                 else { const uint2 n = in_counts[c]; w_nrad = n.x; w_ntot = n.x + n.y; }
                 continue;
             }
@@ -295,8 +331,13 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(DScene sc, DCamera cam, D
     unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
 
     for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
-        const uint32_t n_rad = PRIMARY ? min(ps.chunk, ps.nsamples - chunk * ps.chunk) : in_counts[chunk].x;
+        uint32_t n_rad = PRIMARY ? min(ps.chunk, ps.nsamples - chunk * ps.chunk) : in_counts[chunk].x;
         const size_t base = (size_t)chunk * ps.region;
+        if (PRIMARY && chunk_is_culled(cam, ps, chunk, n_rad)) {
+            // no hit records were written for this chunk: every sample is a miss
+            for (uint32_t i = (uint32_t)lane; i < n_rad; i += 64u) sample_slot[chunk * ps.chunk + i] = kMiss;
+            n_rad = 0u;
+        }
         // ---- compact the rays that hit something (wave64 ballot + prefix popcount into LDS)
         uint32_t cnt = 0u;
         for (uint32_t it = 0; it < n_rad; it += 64u) {

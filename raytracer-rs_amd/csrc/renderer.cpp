@@ -1,6 +1,8 @@
 // renderer.cpp — see renderer.hpp.
 #include "renderer.hpp"
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -99,6 +101,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
 
     // --- acceleration structure (host build, once) + per-triangle normals (calc_normal, mod.rs:198-205)
     build_bvh(scene.tri_verts.data(), scene.tri_geom.data(), ntri, bvh);
+    collect_cull_boxes();
     if (bvh.max_depth > kBvhMaxDepth) { err = "internal: BVH deeper than the traversal stack"; code = MI355RT_E_INVALID; return false; }
     std::vector<float> normals((size_t)std::max(ntri, 1u) * 4, 0.0f);
     for (uint32_t t = 0; t < ntri; ++t) {
@@ -227,6 +230,47 @@ Renderer::~Renderer()
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+// The (padded, half-precision) boxes of the top BVH subtrees, at most kCullRects of them: the boxes the
+// primary-chunk frustum culling tests against.  Breadth-first refinement: always split the largest box.
+void Renderer::collect_cull_boxes()
+{
+    cull_boxes_.clear();
+    if (ntri == 0) return;
+    auto half_to_float = [](uint32_t h) {
+        _Float16 v; uint16_t b = (uint16_t)h; std::memcpy(&v, &b, 2); return (float)v;
+    };
+    struct Item { std::array<float, 6> box; int32_t node; };
+    std::vector<Item> items;
+    Item root; root.node = bvh.root;
+    for (int a = 0; a < 3; ++a) { root.box[a] = bvh.scene_min[a]; root.box[3 + a] = bvh.scene_max[a]; }
+    items.push_back(root);
+    for (;;) {
+        int best = -1; float best_size = -1.0f;
+        for (size_t i = 0; i < items.size(); ++i) {
+            if (items[i].node < 0) continue;                        // a leaf cannot be refined
+            const auto& b = items[i].box;
+            const float size = (b[3] - b[0]) * (b[4] - b[1]) + (b[4] - b[1]) * (b[5] - b[2]) + (b[5] - b[2]) * (b[3] - b[0]);
+            if (size > best_size) { best_size = size; best = (int)i; }
+        }
+        if (best < 0 || items.size() + 1 > kCullRects) break;
+        const BvhNode& n = bvh.nodes[items[best].node];
+        Item c0, c1;
+        for (int a = 0; a < 3; ++a) {
+            c0.box[a] = half_to_float(n.h0[a] & 0xFFFFu); c0.box[3 + a] = half_to_float(n.h0[a] >> 16);
+            c1.box[a] = half_to_float(n.h1[a] & 0xFFFFu); c1.box[3 + a] = half_to_float(n.h1[a] >> 16);
+        }
+        c0.node = n.child0; c1.node = n.child1;
+        items[best] = c0;
+        items.push_back(c1);
+    }
+    for (const Item& it : items) {
+        bool finite = true;
+        for (float v : it.box) if (!std::isfinite(v)) finite = false;
+        if (!finite) { cull_boxes_.clear(); return; }               // coordinates beyond the half range: no culling
+        cull_boxes_.push_back(it.box);
+    }
+}
+
 DCamera Renderer::device_camera() const
 {
     DCamera c;
@@ -235,6 +279,48 @@ DCamera Renderer::device_camera() const
     c.origin[0] = pos.x; c.origin[1] = pos.y; c.origin[2] = pos.z;
     c.max_x = camera.max_x(); c.max_y = camera.max_y();
     c.width = cfg.width; c.height = cfg.height;
+    // Screen-space bounds of the padded scene box for the primary-chunk frustum culling (kernels.hip,
+    // chunk_is_culled).  dir = (dir_x, -dir_y, 1) * R3x3  =>  (dir_x, -dir_y, 1) ~ (p - origin) * R3x3^-1.
+    // Valid only if every corner of the box is in front of the camera; computed in double, widened.
+    c.cull_valid = 0;
+    std::memset(c.cull_rect, 0, sizeof c.cull_rect);
+    if (!cull_boxes_.empty() && !(cfg.flags & MI355RT_FLAG_OCTREE_SEMANTICS) && !getenv("MI355RT_NO_CULL")) {
+        const float* e = c.rot;
+        const double m[3][3] = { { e[0], e[1], e[2] }, { e[4], e[5], e[6] }, { e[8], e[9], e[10] } };
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+                         + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        if (std::fabs(det) > 1e-12) {
+            double inv[3][3];
+            inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det; inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+            inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det; inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+            inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det; inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+            double diag = 0.0;
+            for (int a = 0; a < 3; ++a) diag += (double)(bvh.scene_max[a] - bvh.scene_min[a]) * (bvh.scene_max[a] - bvh.scene_min[a]);
+            const double pad = 1e-3 * std::sqrt(diag) + 1e-6;            // on top of the (already padded) BVH boxes
+            bool front = true;
+            uint32_t n = 0;
+            for (const auto& bx : cull_boxes_) {
+                double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+                for (int k = 0; k < 8 && front; ++k) {
+                    double w[3];
+                    for (int a = 0; a < 3; ++a) w[a] = ((k >> a) & 1 ? bx[3 + a] + pad : bx[a] - pad) - c.origin[a];
+                    const double vx = w[0] * inv[0][0] + w[1] * inv[1][0] + w[2] * inv[2][0];
+                    const double vy = w[0] * inv[0][1] + w[1] * inv[1][1] + w[2] * inv[2][1];
+                    const double vz = w[0] * inv[0][2] + w[1] * inv[1][2] + w[2] * inv[2][2];
+                    if (!(vz > 1e-6 * std::sqrt(diag))) { front = false; break; }
+                    const double dx = vx / vz, dy = -vy / vz;
+                    x0 = std::min(x0, dx); x1 = std::max(x1, dx); y0 = std::min(y0, dy); y1 = std::max(y1, dy);
+                }
+                if (!front) break;
+                const double mx = 1e-4 * (x1 - x0) + 1e-6, my = 1e-4 * (y1 - y0) + 1e-6;
+                c.cull_rect[n][0] = (float)(x0 - mx); c.cull_rect[n][1] = (float)(x1 + mx);
+                c.cull_rect[n][2] = (float)(y0 - my); c.cull_rect[n][3] = (float)(y1 + my);
+                ++n;
+            }
+            if (front) c.cull_valid = n;         // a box behind / around the camera: no culling at all
+            if (getenv("MI355RT_DEBUG_CULL")) { fprintf(stderr, "[mi355rt] cull rects %u front %d max_x %g\n", n, (int)front, c.max_x); for (uint32_t k = 0; k < n; ++k) fprintf(stderr, "   x [%g, %g] y [%g, %g]\n", c.cull_rect[k][0], c.cull_rect[k][1], c.cull_rect[k][2], c.cull_rect[k][3]); }
+        }
+    }
     return c;
 }
 

@@ -2,6 +2,7 @@
 // film of one RayTracer (raytracer/mod.rs:32-47) and schedules the wavefront passes.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <array>
 #include <memory>
 #include <string>
 #include <vector>
@@ -39,6 +40,7 @@ public:
     uint32_t current_row = 0;
     uint32_t nodes_per_sample = 1;
     uint32_t level_first[kMaxLevels + 1] = { 0 };
+    std::vector<std::array<float, 6>> cull_boxes_;   // top BVH subtree boxes for primary-chunk culling
     uint32_t oct_stats_[8] = { 0 };       // reference-exact mode: nodes, inner, leaves, empty, depth, triangle refs
 
 private:
@@ -51,6 +53,7 @@ private:
     bool begin_call();
     bool end_call(uint64_t primary);
     DCamera device_camera() const;
+    void collect_cull_boxes();
     template <class T> bool upload(T*& dptr, const void* src, size_t bytes);
 
     int num_cus_ = 0;
