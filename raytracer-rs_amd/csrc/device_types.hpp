@@ -17,6 +17,8 @@ constexpr uint32_t kRayRecordBytes = 48;
 constexpr uint32_t kShards = 64;            // copies of every contended device word (work cursors, counters)
 constexpr uint32_t kMaxRounds = kMaxRecursions + 2;
 constexpr uint32_t kCullRects = 16;
+constexpr uint32_t kMaxCursors = 64;
+constexpr uint32_t kCtrlWordsPerRound = kMaxCursors * 16384;   // work cursors of one round, 64 KiB apart
 
 struct DMaterial { float r, g, b; uint32_t kind_tex; };       // kind_tex: bit 31 = texture, low bits = texture id
 struct DLight { float px, py, pz, cr, cg, cb; };
@@ -70,6 +72,9 @@ struct DPass {
     uint32_t stack_depth;     // traversal stack rows in LDS (BVH max depth + 1)
     uint32_t leaf_threshold;  // trace kernel: run the triangle code once this many lanes wait at a leaf
     uint32_t refill_threshold; // trace kernel: refill idle lanes once this many are idle
+    uint32_t ncursors;        // trace kernel: number of work cursors (pull modes 4, 5)
+    uint32_t pull_group;      // pull mode 4: consecutive chunks handed out per atomic
+    uint32_t static_eighths;  // pull mode 5: eighths of the chunks dealt statically
     uint32_t pull_mode;       // work distribution experiment switch (1 = default)
     uint32_t list_cap;        // shade kernel: LDS hit-list entries per wave (max radiance rays per chunk)
 };
@@ -79,6 +84,7 @@ struct DCounters {            // one set per render call, zeroed at its start
     unsigned long long inner_execs, leaf_execs;   // COUNT mode: wave-level executions of the inner / leaf section
     unsigned int overflow;
     unsigned int pad;
+    unsigned long long t_first_end, t_last_end, t_sum_end, t_start, n_waves;   // COUNT mode: wave end times (s_memrealtime ticks, 100 MHz)
 };
 
 }  // namespace mi355rt

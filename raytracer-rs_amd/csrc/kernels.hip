@@ -42,31 +42,70 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t global_wave_id() { return blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); }
 
 // Pull the next chunk for this wave (wave-uniform).
-//   mode 2 (default): static striding, no atomics — wave w takes chunks w, w + nwaves, ...; a wave's
-//     chunks lie about one image height apart, which decorrelates their cost.
-//   mode 0: one atomic on a shared cursor per pull.  One device word sustains only ~88 atomics/us:
-//     131 072 chunks per launch put a 1.5 ms floor under every trace launch (4boxes: 6.4 ms -> 1.4 ms
-//     per 16 spp when the atomics went away).
-//   mode 3: first 3/4 of the chunks static, last quarter dynamic (same speed as mode 2 on thai2).
+//   mode 4 (default): dynamic, kCursors cursors.  Cursor k hands out the chunks k, k + kCursors, ... (every
+//     cursor sees a uniform sample of the image, so they run dry together); a wave starts on cursor
+//     (wave % kCursors) and moves on to the next one when its own is dry, each at most once.  One device
+//     word sustains only ~88 atomics/us: with ONE cursor the 131 072 chunk pulls of a launch put a 1.5 ms
+//     floor under every trace launch (4boxes: 6.4 ms -> 1.4 ms per 16 spp without it); eight words at
+//     ~6 pulls/us each are far from that limit.
+//   mode 2: static striding, no atomics (wave w takes chunks w, w + nwaves, ...).  Measured on thai2:
+//     mean wave busy 2.56 ms but last wave done at 3.89 ms — a third of the machine idles on imbalance.
+//   mode 0: one cursor.  mode 3: first 3/4 static, last quarter from one cursor.
 // A relaxed agent-scope load of the cursor in front of the atomic (to skip the end-of-kernel storm)
 // made the kernel 2.5x slower and was dropped (profiles/r01_notes.md).
-__device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, bool& first, uint32_t& chunk)
+constexpr uint32_t kCursorStride = 16384;   // u32 words between cursors (64 KiB): atomics to nearby lines serialise on one memory channel
+struct PullState { bool first = true, in_pool = false; uint32_t shard = 0u, tries = 0u, left = 0u; };
+
+__device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, uint32_t ncursors, uint32_t static_eighths, uint32_t group, PullState& st, uint32_t& chunk)
 {
+    if (mode == 5u) {
+        // hybrid: the first `static_frac`/8 of the chunks are dealt statically (wave w takes w, w + nwaves,
+        // ...: no atomic, no pull latency), the rest comes from the cursor pool below and evens out the
+        // waves' finishing times.
+        const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+        const uint32_t nstatic = (uint32_t)((unsigned long long)nchunks * static_eighths / 8u) / nwaves * nwaves;
+        if (!st.in_pool) {
+            const uint32_t next = st.first ? global_wave_id() : chunk + nwaves;
+            st.first = false;
+            if (next < nstatic) { chunk = next; return true; }
+            st.in_pool = true; st.shard = global_wave_id() % ncursors;
+        }
+        const uint32_t max_tries = ncursors < 8u ? ncursors : 8u;
+        while (st.tries < max_tries) {
+            uint32_t v = 0u;
+            if (lane_id() == 0) v = atomicAdd(&cursor[(size_t)st.shard * kCursorStride], 1u);
+            const uint32_t c = nstatic + st.shard + bcast_first(v) * ncursors;
+            if (c < nchunks) { chunk = c; return true; }
+            st.shard = (st.shard + 1u) % ncursors;
+            ++st.tries;
+        }
+        return false;
+    }
+    if (mode == 4u) {
+        if (st.first) { st.first = false; st.shard = global_wave_id() % ncursors; }
+        else if (st.left > 0u && chunk + 1u < nchunks) { --st.left; ++chunk; return true; }     // rest of the group pulled last time
+        const uint32_t max_tries = ncursors < 8u ? ncursors : 8u;
+        while (st.tries < max_tries) {
+            uint32_t v = 0u;
+            if (lane_id() == 0) v = atomicAdd(&cursor[(size_t)st.shard * kCursorStride], 1u);
+            const uint32_t c = (st.shard + bcast_first(v) * ncursors) * group;
+            if (c < nchunks) { chunk = c; st.left = group - 1u; return true; }
+            st.shard = (st.shard + 1u) % ncursors;      // dry for good
+            ++st.tries;
+        }
+        return false;
+    }
     if (mode == 2u) {
-        if (first) { first = false; chunk = global_wave_id(); }
+        if (st.first) { st.first = false; chunk = global_wave_id(); }
         else chunk += gridDim.x * kWavesPerBlock;
         return chunk < nchunks;
     }
     if (mode == 3u) {
-        // hybrid: the first 3/4 of the chunks are dealt statically (stride = number of waves), the last
-        // quarter dynamically from the cursor, so that one word does not have to serve every pull
         const uint32_t nwaves = gridDim.x * kWavesPerBlock;
         const uint32_t nstatic = (nchunks / 4u * 3u) / nwaves * nwaves;
-        const uint32_t next = first ? global_wave_id() : chunk + nwaves;
-        first = false;
-        if (chunk < nstatic || next < nstatic) {          // still in the static part (chunk == previous one)
-            if (next < nstatic) { chunk = next; return true; }
-        }
+        const uint32_t next = st.first ? global_wave_id() : chunk + nwaves;
+        st.first = false;
+        if (next < nstatic) { chunk = next; return true; }
         uint32_t v = 0u;
         if (lane_id() == 0) v = atomicAdd(cursor, 1u);
         chunk = nstatic + bcast_first(v);
@@ -178,11 +217,13 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
     extern __shared__ int s_stack[];                 // ps.stack_depth rows of kBlock ints
     int* stack = &s_stack[threadIdx.x];
     uint32_t acc_nodes = 0, acc_tris = 0, acc_ie = 0, acc_le = 0;
+    unsigned long long t_begin = 0;
+    if (COUNT) t_begin = __builtin_amdgcn_s_memrealtime();
 
     // wave-uniform work state: the chunk being handed out
     uint32_t w_chunk = 0u, w_next = 0u, w_nrad = 0u, w_ntot = 0u;
     bool exhausted = false;
-    bool w_first = true;
+    PullState w_pull;
     // lane state
     bool busy = false;
     RayState rs;
@@ -201,7 +242,7 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
             if (w_next >= w_ntot) {
                 uint32_t c = 0u;
                 c = w_chunk;
-                if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, w_first, c)) { exhausted = true; break; }
+                if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.static_eighths, ps.pull_group, w_pull, c)) { exhausted = true; break; }
                 w_chunk = c; w_next = 0u;
                 if (PRIMARY) {
                     w_nrad = min(ps.chunk, ps.nsamples - c * ps.chunk);
@@ -273,6 +314,11 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
         if (lane_id() == 0) {
             atomicAdd(&cs->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&cs->tris_tested, (unsigned long long)acc_tris);
             atomicAdd(&cs->inner_execs, (unsigned long long)acc_ie); atomicAdd(&cs->leaf_execs, (unsigned long long)acc_le);
+            // load-balance diagnostics: when did this wave run out of work, relative to the first wave's start
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+            DCounters* c0 = &counters[0];
+            atomicMin(&c0->t_start, t_begin); atomicMin(&c0->t_first_end, t_end); atomicMax(&c0->t_last_end, t_end);
+            atomicAdd(&c0->t_sum_end, t_end - t_begin); atomicAdd(&c0->n_waves, 1ull);
         }
     }
 }

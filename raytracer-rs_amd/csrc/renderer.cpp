@@ -194,7 +194,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_owned_rows_, owned_rows.data(), owned_rows.size() * 4)) return bail();
     if (!upload(d_tmp_rows_, nullptr, 64 * 4)) return bail();
     if (!upload(d_counters_, nullptr, sizeof(DCounters) * kShards)) return bail();
-    if (!upload(d_ctrl_, nullptr, kMaxRounds * 64)) return bail();
+    if (!upload(d_ctrl_, nullptr, kMaxRounds * kCtrlWordsPerRound * 4)) return bail();
     if (!upload(d_debug_color_, nullptr, 16)) return bail();
 
     // queue records one sample can put into one round's output queue (shadow rays of level l + rays of level l+1)
@@ -366,13 +366,16 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
     ps.refill_threshold = 16; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
-    ps.pull_mode = 2u;                  // static striding: no atomics (see pull_chunk)
+    ps.pull_mode = 4u;                  // 8 interleaved cursors (see pull_chunk in kernels.hip)
     if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
+    ps.static_eighths = 4; if (const char* e = getenv("MI355RT_STATIC8")) { int v = atoi(e); if (v >= 0 && v <= 8) ps.static_eighths = (uint32_t)v; }
+    ps.pull_group = 1; if (const char* e = getenv("MI355RT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.pull_group = (uint32_t)v; }
+    ps.ncursors = 64; if (const char* e = getenv("MI355RT_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxCursors) ps.ncursors = (uint32_t)v; }
     const DCamera cam = device_camera();
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
     const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
 
-    HIP_TRY(hipMemsetAsync(d_ctrl_, 0, kMaxRounds * 64, stream_));
+    HIP_TRY(hipMemsetAsync(d_ctrl_, 0, kMaxRounds * kCtrlWordsPerRound * 4, stream_));
     // round r: trace the rays of level r (+ the shadow rays emitted by level r-1), then shade level r
     const uint32_t rounds = cfg.recursions + 2;
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -384,12 +387,27 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
         }
         const void* in_q = r == 0 ? nullptr : d_queue_[(r - 1) & 1];
         const void* in_c = r == 0 ? nullptr : d_chunk_counts_[(r - 1) & 1];
+        const bool balance_dbg = count && getenv("MI355RT_DEBUG_UTIL") && !dscene_.oct_nodes;
+        if (balance_dbg) {       // load-balance diagnostics of this launch (debug only: synchronises)
+            DCounters init{};
+            HIP_TRY(hipMemcpy(&init, d_counters_, sizeof init, hipMemcpyDeviceToHost));
+            init.t_first_end = ~0ull; init.t_start = ~0ull; init.t_last_end = 0; init.t_sum_end = 0; init.n_waves = 0;
+            HIP_TRY(hipMemcpy(d_counters_, &init, sizeof init, hipMemcpyHostToDevice));
+        }
         if (dscene_.oct_nodes)
             HIP_TRY(launch_trace_octree(stream_, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, d_hits_, d_slot_L_, d_film_n_));
         else
-            HIP_TRY(launch_trace(stream_, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, d_hits_, d_ctrl_ + r * 16, d_slot_L_, d_film_n_, d_counters_));
+            HIP_TRY(launch_trace(stream_, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, d_hits_, d_ctrl_ + r * kCtrlWordsPerRound, d_slot_L_, d_film_n_, d_counters_));
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], stream_)); ev_used_ += 2; }
         ++launches_;
+        if (balance_dbg) {
+            DCounters c0{};
+            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(hipMemcpy(&c0, d_counters_, sizeof c0, hipMemcpyDeviceToHost));
+            if (c0.n_waves)
+                fprintf(stderr, "[mi355rt] trace round %u: %llu waves, mean wave busy %.1f us, first wave out of work at %.1f us, last at %.1f us\n", r, c0.n_waves,
+                        (double)c0.t_sum_end / c0.n_waves / 100.0, (double)(c0.t_first_end - c0.t_start) / 100.0, (double)(c0.t_last_end - c0.t_start) / 100.0);
+        }
         if (r <= cfg.recursions)
             HIP_TRY(launch_shade(stream_, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, d_hits_, d_queue_[r & 1], d_chunk_counts_[r & 1], d_slot_L_, d_sample_slot_, d_film_n_, d_counters_));
     }
