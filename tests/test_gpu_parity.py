@@ -344,3 +344,50 @@ def test_octree_mode_other_leaf_sizes_and_frames(pkg, scenes, oracle):
             assert rt.trace_frame_additive() == orc.trace_frame_additive()
         assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0]))
         assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
+
+
+# ---- degenerate inputs ---------------------------------------------------------------------------------------
+def _tiny_scene(scenes, ntri=None, nlights=None):
+    sc = dict(scenes("4boxes"))
+    if ntri is not None:
+        sc["tri_verts"] = sc["tri_verts"][:ntri].copy(); sc["tri_geom"] = sc["tri_geom"][:ntri].copy()
+    if nlights is not None:
+        sc["lights"] = np.concatenate([sc["lights"]] * max(nlights, 1))[:nlights].copy()
+        if nlights > 1:
+            sc["lights"][1, :3] = [-3.0, 4.0, -2.0]; sc["lights"][1, 3:] = [2.0, 5.0, 8.0]
+    return sc
+
+
+@pytest.mark.parametrize("ntri,nlights", [(0, 1), (1, 1), (48, 0), (48, 2), (5, 3)])
+def test_empty_single_triangle_and_multi_light_scenes(pkg, oracle, scenes, ntri, nlights):
+    """no triangles (every ray misses: black film), one triangle (the BVH is a single leaf), no light
+    (every light term black), several lights (accum_color adds them in light order, mod.rs:214-256)."""
+    sc = _tiny_scene(scenes, ntri, nlights)
+    w, h = 48, 40
+    rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=3)
+    orc = oracle.Oracle(sc, w, h, seed=3, flags=oracle.FLAG_BRUTE_FORCE)
+    c = rt.render(3); oc = orc.render(3, nthreads=4)
+    assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+    gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+    assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+    assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
+    if ntri == 0:
+        assert c.primary_hits == 0 and not gs.any()
+    if nlights == 0:
+        assert c.shadow == 0 and not gs.any() and c.bounce > 0
+    # the same through the reference-exact intersector
+    rto = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=3, flags=pkg.FLAG_OCTREE_SEMANTICS)
+    orco = oracle.Oracle(sc, w, h, seed=3)
+    rto.render(2); orco.render(2, nthreads=4)
+    assert np.array_equal(bits(rto.film.pixel_datas()[0]), bits(orco.film()[0]))
+
+
+def test_tiny_and_odd_image_sizes(pkg, oracle, scenes):
+    """1x1, 1xN, Nx1 and sizes that are not multiples of the chunk / stripe / wave sizes."""
+    for w, h in ((1, 1), (1, 37), (37, 1), (257, 3), (33, 65)):
+        rt = make(pkg, scenes, "ico2", w, h, seed=5)
+        orc = oracle.Oracle(scenes("ico2"), w, h, seed=5, flags=oracle.FLAG_BRUTE_FORCE)
+        rt.render(5); orc.render(5, nthreads=4)
+        assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0])), (w, h)
+        assert rt.trace_frame_additive() == orc.trace_frame_additive() == 50 * w
+        assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0])), (w, h)
