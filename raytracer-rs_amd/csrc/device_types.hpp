@@ -72,10 +72,9 @@ struct DPass {
     uint32_t stack_depth;     // traversal stack rows in LDS (BVH max depth + 1)
     uint32_t leaf_threshold;  // trace kernel: run the triangle code once this many lanes wait at a leaf
     uint32_t refill_threshold; // trace kernel: refill idle lanes once this many are idle
-    uint32_t ncursors;        // trace kernel: number of work cursors (pull modes 4, 5)
+    uint32_t ncursors;        // trace kernel: number of work cursors (pull mode 4)
     uint32_t pull_group;      // pull mode 4: consecutive chunks handed out per atomic
-    uint32_t static_eighths;  // pull mode 5: eighths of the chunks dealt statically
-    uint32_t pull_mode;       // work distribution experiment switch (1 = default)
+    uint32_t pull_mode;       // work distribution: 4 = cursors (default), 2 = static striding, 0 = one cursor
     uint32_t list_cap;        // shade kernel: LDS hit-list entries per wave (max radiance rays per chunk)
 };
 

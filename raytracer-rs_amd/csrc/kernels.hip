@@ -42,45 +42,22 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t global_wave_id() { return blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); }
 
 // Pull the next chunk for this wave (wave-uniform).
-//   mode 4 (default): dynamic, kCursors cursors.  Cursor k hands out the chunks k, k + kCursors, ... (every
-//     cursor sees a uniform sample of the image, so they run dry together); a wave starts on cursor
-//     (wave % kCursors) and moves on to the next one when its own is dry, each at most once.  One device
-//     word sustains only ~88 atomics/us: with ONE cursor the 131 072 chunk pulls of a launch put a 1.5 ms
-//     floor under every trace launch (4boxes: 6.4 ms -> 1.4 ms per 16 spp without it); eight words at
-//     ~6 pulls/us each are far from that limit.
+//   mode 4 (default): dynamic, ps.ncursors (64) cursors that lie 64 KiB apart.  Cursor k hands out the
+//     chunks k, k + ncursors, ... (every cursor sees a uniform sample of the image, so they run dry
+//     together); a wave starts on cursor (wave % ncursors) and moves on to the next one when its own is
+//     dry, at most 8 of them.  Returning atomics to ONE word — or to several words in one cache line, or
+//     256 B apart — serialise at ~88/us for the whole chip: with one cursor the 131 072 chunk pulls of a
+//     launch put a 1.5 ms floor under every trace launch.
 //   mode 2: static striding, no atomics (wave w takes chunks w, w + nwaves, ...).  Measured on thai2:
 //     mean wave busy 2.56 ms but last wave done at 3.89 ms — a third of the machine idles on imbalance.
-//   mode 0: one cursor.  mode 3: first 3/4 static, last quarter from one cursor.
-// A relaxed agent-scope load of the cursor in front of the atomic (to skip the end-of-kernel storm)
-// made the kernel 2.5x slower and was dropped (profiles/r01_notes.md).
+//   mode 0: one cursor (kept for the A/B in profiles/r01_notes.md).
+// Tried and dropped: a relaxed agent-scope load in front of the atomic (2.5x slower), 3/4 static + a
+// dynamic rest, several chunks per pull, draining more than 8 cursors, heaviest-chunks-first order.
 constexpr uint32_t kCursorStride = 16384;   // u32 words between cursors (64 KiB): atomics to nearby lines serialise on one memory channel
-struct PullState { bool first = true, in_pool = false; uint32_t shard = 0u, tries = 0u, left = 0u; };
+struct PullState { bool first = true; uint32_t shard = 0u, tries = 0u, left = 0u; };
 
-__device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, uint32_t ncursors, uint32_t static_eighths, uint32_t group, PullState& st, uint32_t& chunk)
+__device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, uint32_t ncursors, uint32_t group, PullState& st, uint32_t& chunk)
 {
-    if (mode == 5u) {
-        // hybrid: the first `static_frac`/8 of the chunks are dealt statically (wave w takes w, w + nwaves,
-        // ...: no atomic, no pull latency), the rest comes from the cursor pool below and evens out the
-        // waves' finishing times.
-        const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-        const uint32_t nstatic = (uint32_t)((unsigned long long)nchunks * static_eighths / 8u) / nwaves * nwaves;
-        if (!st.in_pool) {
-            const uint32_t next = st.first ? global_wave_id() : chunk + nwaves;
-            st.first = false;
-            if (next < nstatic) { chunk = next; return true; }
-            st.in_pool = true; st.shard = global_wave_id() % ncursors;
-        }
-        const uint32_t max_tries = ncursors < 8u ? ncursors : 8u;
-        while (st.tries < max_tries) {
-            uint32_t v = 0u;
-            if (lane_id() == 0) v = atomicAdd(&cursor[(size_t)st.shard * kCursorStride], 1u);
-            const uint32_t c = nstatic + st.shard + bcast_first(v) * ncursors;
-            if (c < nchunks) { chunk = c; return true; }
-            st.shard = (st.shard + 1u) % ncursors;
-            ++st.tries;
-        }
-        return false;
-    }
     if (mode == 4u) {
         if (st.first) { st.first = false; st.shard = global_wave_id() % ncursors; }
         else if (st.left > 0u && chunk + 1u < nchunks) { --st.left; ++chunk; return true; }     // rest of the group pulled last time
@@ -98,17 +75,6 @@ __device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, u
     if (mode == 2u) {
         if (st.first) { st.first = false; chunk = global_wave_id(); }
         else chunk += gridDim.x * kWavesPerBlock;
-        return chunk < nchunks;
-    }
-    if (mode == 3u) {
-        const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-        const uint32_t nstatic = (nchunks / 4u * 3u) / nwaves * nwaves;
-        const uint32_t next = st.first ? global_wave_id() : chunk + nwaves;
-        st.first = false;
-        if (next < nstatic) { chunk = next; return true; }
-        uint32_t v = 0u;
-        if (lane_id() == 0) v = atomicAdd(cursor, 1u);
-        chunk = nstatic + bcast_first(v);
         return chunk < nchunks;
     }
     uint32_t v = 0u;
@@ -242,7 +208,7 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
             if (w_next >= w_ntot) {
                 uint32_t c = 0u;
                 c = w_chunk;
-                if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.static_eighths, ps.pull_group, w_pull, c)) { exhausted = true; break; }
+                if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c)) { exhausted = true; break; }
                 w_chunk = c; w_next = 0u;
                 if (PRIMARY) {
                     w_nrad = min(ps.chunk, ps.nsamples - c * ps.chunk);

@@ -368,7 +368,6 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     ps.refill_threshold = 16; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
     ps.pull_mode = 4u;                  // 8 interleaved cursors (see pull_chunk in kernels.hip)
     if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
-    ps.static_eighths = 4; if (const char* e = getenv("MI355RT_STATIC8")) { int v = atoi(e); if (v >= 0 && v <= 8) ps.static_eighths = (uint32_t)v; }
     ps.pull_group = 1; if (const char* e = getenv("MI355RT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.pull_group = (uint32_t)v; }
     ps.ncursors = 64; if (const char* e = getenv("MI355RT_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxCursors) ps.ncursors = (uint32_t)v; }
     const DCamera cam = device_camera();
