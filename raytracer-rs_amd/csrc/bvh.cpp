@@ -24,7 +24,7 @@ struct Box {
 struct TmpNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; uint32_t depth = 0; };
 
 static uint32_t g_max_leaf = kBvhMaxLeaf;
-static float g_trav_cost = 1.5f;
+static float g_trav_cost = 0.5f;
 
 struct Builder {
     const float* verts;
@@ -137,7 +137,7 @@ void pack_box(const Box& box, float pad, uint32_t out[3])
 void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out)
 {
     out = Bvh();
-    g_max_leaf = kBvhMaxLeaf; g_trav_cost = 1.5f;
+    g_max_leaf = kBvhMaxLeaf; g_trav_cost = 0.5f;   // measured: smaller leaves win (profiles/r01_notes.md)
     if (const char* e = std::getenv("MI355RT_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) g_max_leaf = (uint32_t)v; }
     if (const char* e = std::getenv("MI355RT_TRAV_COST")) { float v = (float)std::atof(e); if (v >= 0.0f) g_trav_cost = v; }
     if (ntri == 0) {
