@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
 
 // ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
 template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
+__global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       const float4* __restrict__ hits,
                                                       float4* __restrict__ out_q, uint2* __restrict__ out_counts,
@@ -378,7 +378,14 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(DScene sc, DCamera cam, D
             // reached, must read back as black (mod.rs:99-100, 170)
             const uint32_t per = ps.nodes_per_sample * sc.nlights * 3u;
             float* z = slot_L + (size_t)chunk * ps.chunk * per;
-            for (uint32_t k = (uint32_t)lane; k < cnt * per; k += 64u) z[k] = 0.0f;
+            const uint32_t total = cnt * per;
+            if ((((size_t)chunk * ps.chunk * per) & 3u) == 0u) {               // 16-byte aligned chunk base: wide stores
+                float4* z4 = (float4*)z;
+                for (uint32_t k = (uint32_t)lane; k < total / 4u; k += 64u) z4[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (uint32_t k = (total & ~3u) + (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
+            } else {
+                for (uint32_t k = (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t out_front = 0u, out_back = 0u;
