@@ -179,12 +179,12 @@ def cpu_baseline(ge, scene):
     rays = tot["primary"] + tot["bounce"] + tot["shadow"]
     # single-thread rate on a smaller sample (the reference's real threading model, mod.rs:80-117)
     t1 = time.perf_counter()
-    c1 = orc.render(1, nthreads=1, rows=(536, 544))
+    c1 = orc.render(1, nthreads=1, rows=(508, 572))
     dt1 = time.perf_counter() - t1
     rays1 = c1["primary"] + c1["bounce"] + c1["shadow"]
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": ncores, "kind": "port",
             "sample": "%d spp of the same 1920x1080 thai2 frame (%d primary samples, %.1f s), octree oracle at 70 tris/leaf, %d threads; "
-                      "single_thread_value = 8 rows x 1 spp on 1 thread" % (frames, tot["primary"], dt, ncores),
+                      "single_thread_value = 64 rows x 1 spp on 1 thread" % (frames, tot["primary"], dt, ncores),
             "primary_mrays_per_s": round(tot["primary"] / dt / 1e6, 4),
             "single_thread_value": round(rays1 / dt1 / 1e6, 4)}
 
