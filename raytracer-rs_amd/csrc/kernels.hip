@@ -194,8 +194,8 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
     // lane state
     bool busy = false;
     RayState rs;
-    size_t rec = 0;                                  // radiance: hit-record index; shadow: float index into slot_L
-    f3 sh_L = mk3(0, 0, 0);                          // shadow: the light term the ray carries
+    uint32_t rec = 0;                                // radiance: hit-record index; shadow: float index into slot_L (both < 2^32)
+    // a shadow ray never touches rs.t / rs.u / rs.v (only radiance rays record a hit): they carry its light term
     ray_init(rs, mk3(0, 0, 0), mk3(0, 0, 1), false, sc.root);
 
     for (;;) {
@@ -225,24 +225,25 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
                 const uint32_t i = w_next + rank;
                 f3 o, d;
                 bool shadow = false;
+                float4 sh_L4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (PRIMARY) {
                     uint32_t pixel, sampleno;
                     primary_sample(cam, ps, film_n, w_chunk * ps.chunk + i, pixel, sampleno, o, d);
-                    rec = (size_t)w_chunk * ps.region + i;
+                    rec = w_chunk * ps.region + i;
                 } else {
                     const size_t r = record_index(ps, w_chunk, i, w_nrad);
                     const float4 r0 = in_q[3 * r], r1 = in_q[3 * r + 1];
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
                     shadow = i >= w_nrad;
-                    rec = r;
+                    rec = (uint32_t)r;
                     if (shadow) {       // keep what the finish needs in registers: no load when the ray ends
-                        const float4 r2 = in_q[3 * r + 2];
-                        sh_L = mk3(r2.x, r2.y, r2.z);
+                        sh_L4 = in_q[3 * r + 2];
                         const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
-                        rec = 3ull * (((size_t)slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
+                        rec = 3u * ((slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
                     }
                 }
                 ray_init(rs, o, d, shadow, sc.root);
+                if (shadow) { rs.t = sh_L4.x; rs.u = sh_L4.y; rs.v = sh_L4.z; }
                 busy = true;
             }
             w_next += min((uint32_t)__popcll(idle), avail);
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
                     hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
                 } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
                     float* dst = slot_L + rec;
-                    dst[0] = sh_L.x; dst[1] = sh_L.y; dst[2] = sh_L.z;
+                    dst[0] = rs.t; dst[1] = rs.u; dst[2] = rs.v;
                 }
             }
         }

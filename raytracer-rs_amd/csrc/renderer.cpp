@@ -333,7 +333,10 @@ bool Renderer::ensure_pass_capacity(size_t nsamples)
     pass_capacity_ = 0;
     const size_t nchunks = (nsamples + chunk_ - 1) / chunk_;
     const size_t records = nchunks * chunk_ * records_per_sample_;
-    if (nsamples > 0x7FFFFFFFull) { last_error = "pass too large"; return false; }
+    // the kernels index hit records and light-term floats with 32 bits
+    if (nsamples > 0x7FFFFFFFull || records > 0xFFFFFFFFull || nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 3ull > 0xFFFFFFFFull) {
+        last_error = "pass too large"; return false;
+    }
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMalloc(&d_queue_[i], records * kRayRecordBytes));
         if (d_chunk_counts_[i]) { (void)hipFree(d_chunk_counts_[i]); d_chunk_counts_[i] = nullptr; }
