@@ -57,6 +57,7 @@ struct DPass {
     // primary-sample enumeration: thread i -> s = i / npix, p = i % npix,
     // row = rows[row0 + p / width], x = p % width, pixel = row * width + x
     const uint32_t* rows;
+    uint32_t* hit_prim;       // per radiance record: triangle hit or 0xFFFFFFFF (the 16-byte hit record is written for hits only)
     uint32_t row0;
     uint32_t npix;            // pixels in this pass (rows_in_pass * width)
     uint32_t nsamples;        // npix * samples per pixel in this pass

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
             if (fin) {
                 busy = false;
                 if (!rs.shadow) {
-                    hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
+                    ps.hit_prim[rec] = rs.prim;                                 // 4 B for every ray, the 16 B record only for hits
+                    if (rs.prim != kMiss) hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
                 } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
                     float* dst = slot_L + rec;
                     dst[0] = rs.t; dst[1] = rs.u; dst[2] = rs.v;
@@ -328,7 +329,8 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
             float t, u, v; uint32_t prim;
             octree_intersect(sc, o, d, t, u, v, prim);
             if (i < n_rad) {
-                hits[r] = make_float4(t, u, v, __uint_as_float(prim));
+                ps.hit_prim[r] = prim;
+                if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
             } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {          // not blocked, mod.rs:226-232
                 const float4 r1 = in_q[3 * r + 1], r2 = in_q[3 * r + 2];
                 const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene s
         uint32_t cnt = 0u;
         for (uint32_t it = 0; it < n_rad; it += 64u) {
             const uint32_t i = it + (uint32_t)lane;
-            const bool valid = i < n_rad && __float_as_uint(hits[base + i].w) != kMiss;
+            const bool valid = i < n_rad && ps.hit_prim[base + i] != kMiss;
             uint32_t n_new;
             const uint32_t pos = wave_append(valid, cnt, n_new);
             if (valid) list[pos] = i;

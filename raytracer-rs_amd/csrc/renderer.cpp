@@ -224,6 +224,7 @@ Renderer::~Renderer()
     if (d_sample_slot_) (void)hipFree(d_sample_slot_);
     for (int i = 0; i < 2; ++i) if (d_chunk_counts_[i]) (void)hipFree(d_chunk_counts_[i]);
     if (d_hits_) (void)hipFree(d_hits_);
+    if (d_hit_prim_) (void)hipFree(d_hit_prim_);
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -344,6 +345,8 @@ bool Renderer::ensure_pass_capacity(size_t nsamples)
     }
     if (d_hits_) { (void)hipFree(d_hits_); d_hits_ = nullptr; }
     HIP_TRY(hipMalloc(&d_hits_, records * 16));
+    if (d_hit_prim_) { (void)hipFree(d_hit_prim_); d_hit_prim_ = nullptr; }
+    HIP_TRY(hipMalloc((void**)&d_hit_prim_, records * 4));
     HIP_TRY(hipMalloc((void**)&d_slot_L_, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
     if (d_sample_slot_) { (void)hipFree(d_sample_slot_); d_sample_slot_ = nullptr; }
     HIP_TRY(hipMalloc((void**)&d_sample_slot_, nchunks * chunk_ * 4));
@@ -366,6 +369,7 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
     ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
     ps.chunk = chunk_; ps.nchunks = (uint32_t)((nsamples + chunk_ - 1) / chunk_); ps.region = chunk_ * records_per_sample_;
+    ps.hit_prim = d_hit_prim_;
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
     ps.refill_threshold = 16; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }

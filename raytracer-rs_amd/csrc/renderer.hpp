@@ -72,7 +72,8 @@ private:
     float* d_debug_color_ = nullptr;
     void* d_queue_[2] = { nullptr, nullptr };
     uint32_t* d_chunk_counts_[2] = { nullptr, nullptr };   // rays per chunk in each queue
-    void* d_hits_ = nullptr;             // hit records of the round being processed (16 B per queue record)
+    void* d_hits_ = nullptr;
+    uint32_t* d_hit_prim_ = nullptr;             // hit records of the round being processed (16 B per queue record)
     uint32_t chunk_ = 256;               // primary samples per work chunk
     uint32_t max_level_nodes_ = 1;
     uint32_t leaf_threshold_ = 16;
