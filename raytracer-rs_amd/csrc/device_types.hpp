@@ -9,7 +9,8 @@ constexpr uint32_t kSampleMax = 65535;
 constexpr uint32_t kMaxRecursions = 3;
 constexpr uint32_t kMaxLevels = kMaxRecursions + 1;
 
-// Ray-queue record, 48 bytes = 3 x float4:
+// Ray-queue record, 48 bytes = 3 x float4, stored as three planes (q0 of every record, then q1, then q2)
+// so that a wave's 64 consecutive records are 1 KiB contiguous per plane:
 //   q0 = (o.x, o.y, o.z, d.x)   q1 = (d.y, d.z, slot, meta)
 //   q2 = radiance ray: (pixel, sample#, -, -) as bits;  shadow ray: (L.r, L.g, L.b, -)
 // meta: bit 0 kind (0 radiance, 1 shadow) | level << 4 | node << 8 | light << 24
@@ -57,6 +58,7 @@ struct DPass {
     // primary-sample enumeration: thread i -> s = i / npix, p = i % npix,
     // row = rows[row0 + p / width], x = p % width, pixel = row * width + x
     const uint32_t* rows;
+    size_t qstride;           // records per queue: a queue is three float4 planes q0[], q1[], q2[] (structure of arrays)
     uint32_t* hit_prim;       // per radiance record: triangle hit or 0xFFFFFFFF (the 16-byte hit record is written for hits only)
     uint32_t row0;
     uint32_t npix;            // pixels in this pass (rows_in_pass * width)

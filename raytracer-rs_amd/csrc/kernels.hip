@@ -232,12 +232,12 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
                     rec = w_chunk * ps.region + i;
                 } else {
                     const size_t r = record_index(ps, w_chunk, i, w_nrad);
-                    const float4 r0 = in_q[3 * r], r1 = in_q[3 * r + 1];
+                    const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
                     shadow = i >= w_nrad;
                     rec = (uint32_t)r;
                     if (shadow) {       // keep what the finish needs in registers: no load when the ray ends
-                        sh_L4 = in_q[3 * r + 2];
+                        sh_L4 = in_q[2 * ps.qstride + r];
                         const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
                         rec = 3u * ((slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
                     }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
                 r = (size_t)chunk * ps.region + i;
             } else {
                 r = record_index(ps, chunk, i, n_rad);
-                const float4 r0 = in_q[3 * r], r1 = in_q[3 * r + 1];
+                const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
                 o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
             }
             float t, u, v; uint32_t prim;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
                 ps.hit_prim[r] = prim;
                 if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
             } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {          // not blocked, mod.rs:226-232
-                const float4 r1 = in_q[3 * r + 1], r2 = in_q[3 * r + 2];
+                const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
                 const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
                 float* dst = slot_L + 3ull * (((size_t)slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
                 dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene s
                     slot = chunk * ps.chunk + j + (uint32_t)lane;       // == sample_slot[chunk * ps.chunk + i]
                     primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
                 } else {
-                    const float4 r0 = in_q[3 * (base + i)], r1 = in_q[3 * (base + i) + 1], r2 = in_q[3 * (base + i) + 2];
+                    const float4 r0 = in_q[base + i], r1 = in_q[ps.qstride + base + i], r2 = in_q[2 * ps.qstride + base + i];
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
                     slot = __float_as_uint(r1.z); node = (__float_as_uint(r1.w) >> 8) & 0xFFFFu;
                     pixel = __float_as_uint(r2.x); sampleno = __float_as_uint(r2.y);
@@ -439,9 +439,9 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene s
                 const uint32_t oi = wave_append(want, out_back, n_new);
                 if (want && out_front + oi < ps.region) {
                     const size_t r = base + (ps.region - 1u - oi);
-                    out_q[3 * r] = make_float4(so.x, so.y, so.z, sd.x);
-                    out_q[3 * r + 1] = make_float4(sd.y, sd.z, __uint_as_float(slot), __uint_as_float(1u | (level << 4) | (node << 8) | (li << 24)));
-                    out_q[3 * r + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+                    out_q[r] = make_float4(so.x, so.y, so.z, sd.x);
+                    out_q[ps.qstride + r] = make_float4(sd.y, sd.z, __uint_as_float(slot), __uint_as_float(1u | (level << 4) | (node << 8) | (li << 24)));
+                    out_q[2 * ps.qstride + r] = make_float4(c.x, c.y, c.z, 0.0f);
                 }
             }
             // ---- reflection rays, mod.rs:146-158 + 178-196
@@ -470,9 +470,9 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene s
                     const uint32_t oi = wave_append(active, out_front, n_new);
                     if (active && oi + out_back < ps.region + 0u) {
                         const size_t r = base + oi;
-                        out_q[3 * r] = make_float4(bo.x, bo.y, bo.z, bd.x);
-                        out_q[3 * r + 1] = make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8)));
-                        out_q[3 * r + 2] = make_float4(__uint_as_float(pixel), __uint_as_float(sampleno), 0.0f, 0.0f);
+                        out_q[r] = make_float4(bo.x, bo.y, bo.z, bd.x);
+                        out_q[ps.qstride + r] = make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8)));
+                        out_q[2 * ps.qstride + r] = make_float4(__uint_as_float(pixel), __uint_as_float(sampleno), 0.0f, 0.0f);
                     }
                 }
             }
