@@ -146,7 +146,10 @@ def main():
             "primary_mrays_per_s": round(primary / elapsed / 1e6, 2),
             "rays_per_frame": {"primary": primary / args.steps, "bounce": bounce / args.steps, "shadow": shadow / args.steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(),
+                         "traffic_source": "offline rocprofv3 --pmc passes of this command (profiles/r01_pmc_traffic_summary.txt): "
+                                           "(2 x FETCH_SIZE + WRITE_SIZE) per secondary trace launch",
+                         "algorithmic_bytes_per_launch": round(total_rays * bytes_per_ray / max(launches, 1), 1),
                          "kernel": "trace_kernel", "launches": int(launches), "avg_launch_ms": round(trace_ms / max(launches, 1), 4),
                          "bytes_per_ray": round(bytes_per_ray, 1), "node_bytes": node_bytes, "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
                          "note": "logical bytes (SURVEY.md 8d); the 1.5 MB scene is cache-resident, measured HBM traffic is queues + film only"},
@@ -157,6 +160,30 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic_per_launch():
+    """HBM bytes per secondary trace launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command, profiles/r01_pmc_traffic_summary.txt): (2 x FETCH_SIZE + WRITE_SIZE)
+    x 1024 / dispatches — FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.txt")
+    try:
+        text = open(path).read()
+    except OSError:
+        return None
+    vals = {}
+    section = None
+    lines = text.splitlines()
+    for i, line in enumerate(lines):
+        if line.startswith("== "):
+            section = line[3:].strip()
+        if line.startswith("S:trace_kernel<false, fals") and section in ("pmc_fetch", "pmc_write") and i + 1 < len(lines):
+            n = int(line.split("dispatches")[1])
+            name, v = lines[i + 1].split()
+            vals[name] = float(v) * 1024.0 / n
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+    return None
 
 
 def cpu_baseline(ge, scene):
