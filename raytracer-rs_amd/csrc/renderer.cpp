@@ -218,13 +218,7 @@ Renderer::~Renderer()
     if (hipSetDevice(cfg.device) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (void* p : allocs_) (void)hipFree(p);
-    if (d_queue_[0]) (void)hipFree(d_queue_[0]);
-    if (d_queue_[1]) (void)hipFree(d_queue_[1]);
-    if (d_slot_L_) (void)hipFree(d_slot_L_);
-    if (d_sample_slot_) (void)hipFree(d_sample_slot_);
-    for (int i = 0; i < 2; ++i) if (d_chunk_counts_[i]) (void)hipFree(d_chunk_counts_[i]);
-    if (d_hits_) (void)hipFree(d_hits_);
-    if (d_hit_prim_) (void)hipFree(d_hit_prim_);
+    free_pass_buffers();
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -325,31 +319,41 @@ DCamera Renderer::device_camera() const
     return c;
 }
 
+#define HIP_ALLOC(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { alloc_failed_ = e__ == hipErrorOutOfMemory; free_pass_buffers(); return fail(e__, #expr); } } while (0)
+
+void Renderer::free_pass_buffers()
+{
+    for (int i = 0; i < 2; ++i) {
+        if (d_queue_[i]) { (void)hipFree(d_queue_[i]); d_queue_[i] = nullptr; }
+        if (d_chunk_counts_[i]) { (void)hipFree(d_chunk_counts_[i]); d_chunk_counts_[i] = nullptr; }
+    }
+    if (d_slot_L_) { (void)hipFree(d_slot_L_); d_slot_L_ = nullptr; }
+    if (d_sample_slot_) { (void)hipFree(d_sample_slot_); d_sample_slot_ = nullptr; }
+    if (d_hits_) { (void)hipFree(d_hits_); d_hits_ = nullptr; }
+    if (d_hit_prim_) { (void)hipFree(d_hit_prim_); d_hit_prim_ = nullptr; }
+    pass_capacity_ = 0;
+}
+
 bool Renderer::ensure_pass_capacity(size_t nsamples)
 {
+    alloc_failed_ = false;
     if (nsamples <= pass_capacity_) return true;
     HIP_TRY(hipStreamSynchronize(stream_));
-    for (int i = 0; i < 2; ++i) if (d_queue_[i]) { (void)hipFree(d_queue_[i]); d_queue_[i] = nullptr; }
-    if (d_slot_L_) { (void)hipFree(d_slot_L_); d_slot_L_ = nullptr; }
-    pass_capacity_ = 0;
+    free_pass_buffers();
     const size_t nchunks = (nsamples + chunk_ - 1) / chunk_;
     const size_t records = nchunks * chunk_ * records_per_sample_;
     // the kernels index hit records and light-term floats with 32 bits
     if (nsamples > 0x7FFFFFFFull || records > 0xFFFFFFFFull || nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 3ull > 0xFFFFFFFFull) {
-        last_error = "pass too large"; return false;
+        last_error = "pass too large"; alloc_failed_ = true; return false;     // the caller retries with a smaller pass
     }
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc(&d_queue_[i], records * kRayRecordBytes));
-        if (d_chunk_counts_[i]) { (void)hipFree(d_chunk_counts_[i]); d_chunk_counts_[i] = nullptr; }
-        HIP_TRY(hipMalloc((void**)&d_chunk_counts_[i], nchunks * 8));
+        HIP_ALLOC(hipMalloc(&d_queue_[i], records * kRayRecordBytes));
+        HIP_ALLOC(hipMalloc((void**)&d_chunk_counts_[i], nchunks * 8));
     }
-    if (d_hits_) { (void)hipFree(d_hits_); d_hits_ = nullptr; }
-    HIP_TRY(hipMalloc(&d_hits_, records * 16));
-    if (d_hit_prim_) { (void)hipFree(d_hit_prim_); d_hit_prim_ = nullptr; }
-    HIP_TRY(hipMalloc((void**)&d_hit_prim_, records * 4));
-    HIP_TRY(hipMalloc((void**)&d_slot_L_, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
-    if (d_sample_slot_) { (void)hipFree(d_sample_slot_); d_sample_slot_ = nullptr; }
-    HIP_TRY(hipMalloc((void**)&d_sample_slot_, nchunks * chunk_ * 4));
+    HIP_ALLOC(hipMalloc(&d_hits_, records * 16));
+    HIP_ALLOC(hipMalloc((void**)&d_hit_prim_, records * 4));
+    HIP_ALLOC(hipMalloc((void**)&d_slot_L_, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
+    HIP_ALLOC(hipMalloc((void**)&d_sample_slot_, nchunks * chunk_ * 4));
     pass_capacity_ = nsamples;
     queue_records_ = records;
     return true;
@@ -491,13 +495,24 @@ bool Renderer::render(uint32_t spp)
     if (nrows && spp) {
         size_t target = cfg.samples_per_pass ? (size_t)cfg.samples_per_pass * cfg.width * nrows : ((size_t)32 << 20);
         if (const char* e = getenv("MI355RT_PASS_SAMPLES")) { long v = atol(e); if (v >= 1024) target = (size_t)v; }
-        uint32_t rows_per_pass = (uint32_t)std::min<size_t>(nrows, std::max<size_t>(1, target / cfg.width));
-        uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, target / ((size_t)rows_per_pass * cfg.width)));
-        if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
-        for (uint32_t done = 0; done < spp; done += k) {
-            const uint32_t kk = std::min(k, spp - done);
-            for (uint32_t r0 = 0; r0 < nrows; r0 += rows_per_pass)
-                if (!run_pass(d_owned_rows_, r0, std::min(rows_per_pass, nrows - r0), kk, false, 0, 0)) return false;
+        // The pass buffers (two ray queues, hit records, light terms: ~530 B per sample) are sized for the
+        // largest pass.  If the device cannot hold them (another tenant, a 16 GB part), halve the pass and
+        // try again; results do not depend on how samples are batched into passes.
+        for (;;) {
+            const uint32_t rows_per_pass = (uint32_t)std::min<size_t>(nrows, std::max<size_t>(1, target / cfg.width));
+            uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, target / ((size_t)rows_per_pass * cfg.width)));
+            if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
+            if (ensure_pass_capacity((size_t)rows_per_pass * cfg.width * std::min(k, spp))) {
+                for (uint32_t done = 0; done < spp; done += k) {
+                    const uint32_t kk = std::min(k, spp - done);
+                    for (uint32_t r0 = 0; r0 < nrows; r0 += rows_per_pass)
+                        if (!run_pass(d_owned_rows_, r0, std::min(rows_per_pass, nrows - r0), kk, false, 0, 0)) return false;
+                }
+                break;
+            }
+            if (!alloc_failed_ || cfg.samples_per_pass || target <= ((size_t)64 << 10)) return false;
+            (void)hipGetLastError();
+            target /= 2;
         }
     }
     return end_call((uint64_t)nrows * cfg.width * spp);

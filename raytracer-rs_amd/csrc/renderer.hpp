@@ -49,6 +49,7 @@ private:
     bool bind();
     bool fail(hipError_t e, const char* what);
     bool ensure_pass_capacity(size_t nsamples);
+    void free_pass_buffers();
     bool run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample);
     bool begin_call();
     bool end_call(uint64_t primary);
@@ -79,6 +80,7 @@ private:
     uint32_t leaf_threshold_ = 16;
     float* d_slot_L_ = nullptr;
     uint32_t* d_sample_slot_ = nullptr;  // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
+    bool alloc_failed_ = false;          // the last ensure_pass_capacity failure was an out-of-memory
     size_t pass_capacity_ = 0;           // samples
     size_t queue_records_ = 0;
     uint32_t records_per_sample_ = 1;
