@@ -110,6 +110,8 @@ ABI = [
     ("mi355rt_camera_get_ray", C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_float, C.c_float, _F]),
     ("mi355rt_set_seed", C.c_int, [_H, C.c_uint64]),
     ("mi355rt_set_flags", C.c_int, [_H, C.c_uint32]),
+    ("mi355rt_set_slices", C.c_int, [_H, C.c_uint32]),
+    ("mi355rt_get_slices", C.c_uint32, [_H]),
     ("mi355rt_intersect_rays", C.c_int, [_H, _F, C.c_size_t, _F, _U]),
     ("mi355rt_occluded_rays", C.c_int, [_H, _F, C.c_size_t, C.POINTER(C.c_uint8)]),
     ("mi355rt_get_sample_table", C.c_int, [_H, _F]),
@@ -268,6 +270,13 @@ class RayTracer:
 
     def set_flags(self, flags):
         self._check(lib().mi355rt_set_flags(self._h, flags))
+
+    def set_slices(self, slices):
+        """Concurrent frame slices of render() (1..8); results do not depend on it."""
+        self._check(lib().mi355rt_set_slices(self._h, slices))
+
+    def get_slices(self):
+        return int(lib().mi355rt_get_slices(self._h))
 
     def owned_rows(self):
         n = lib().mi355rt_owned_rows(self._h)

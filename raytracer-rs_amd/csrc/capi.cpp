@@ -228,6 +228,14 @@ int mi355rt_set_flags(mi355rt_handle* h, uint32_t flags)
     return MI355RT_OK;
 }
 
+int mi355rt_set_slices(mi355rt_handle* h, uint32_t slices)
+{
+    if (!h || slices < 1 || slices > 8) return MI355RT_E_INVALID;
+    h->r->slices = slices; h->r->slices_explicit = true;
+    return MI355RT_OK;
+}
+uint32_t mi355rt_get_slices(const mi355rt_handle* h) { return h ? h->r->slices : 0; }
+
 int mi355rt_intersect_rays(mi355rt_handle* h, const float* rays6, size_t n, float* tuv, uint32_t* prim)
 {
     if (!h || (n && (!rays6 || !tuv || !prim))) return MI355RT_E_INVALID;

@@ -194,7 +194,14 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_owned_rows_, owned_rows.data(), owned_rows.size() * 4)) return bail();
     if (!upload(d_tmp_rows_, nullptr, 64 * 4)) return bail();
     if (!upload(d_counters_, nullptr, sizeof(DCounters) * kShards)) return bail();
-    if (!upload(d_ctrl_, nullptr, kMaxRounds * kCtrlWordsPerRound * 4)) return bail();
+    slices_[0].stream = stream_;
+    for (uint32_t i = 0; i < kMaxSlices; ++i) {
+        if (i && hipStreamCreateWithFlags(&slices_[i].stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+        if (hipEventCreateWithFlags(&slices_[i].done, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
+        if (!upload(slices_[i].d_ctrl, nullptr, kMaxRounds * kCtrlWordsPerRound * 4)) return bail();
+        if (!upload(slices_[i].d_rows, nullptr, (size_t)cfg.height * 4)) return bail();
+    }
+    if (const char* e = getenv("MI355RT_SLICES")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxSlices) slices = (uint32_t)v; }
     if (!upload(d_debug_color_, nullptr, 16)) return bail();
 
     // queue records one sample can put into one round's output queue (shadow rays of level l + rays of level l+1)
@@ -217,6 +224,10 @@ Renderer::~Renderer()
 {
     if (hipSetDevice(cfg.device) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
+    for (uint32_t i = 0; i < kMaxSlices; ++i) {
+        if (i && slices_[i].stream) { (void)hipStreamSynchronize(slices_[i].stream); (void)hipStreamDestroy(slices_[i].stream); }
+        if (slices_[i].done) (void)hipEventDestroy(slices_[i].done);
+    }
     for (void* p : allocs_) (void)hipFree(p);
     free_pass_buffers();
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
@@ -323,23 +334,30 @@ DCamera Renderer::device_camera() const
 
 void Renderer::free_pass_buffers()
 {
-    for (int i = 0; i < 2; ++i) {
-        if (d_queue_[i]) { (void)hipFree(d_queue_[i]); d_queue_[i] = nullptr; }
-        if (d_chunk_counts_[i]) { (void)hipFree(d_chunk_counts_[i]); d_chunk_counts_[i] = nullptr; }
+    for (Slice& sl : slices_) {
+        for (int i = 0; i < 2; ++i) {
+            if (sl.d_queue[i]) { (void)hipFree(sl.d_queue[i]); sl.d_queue[i] = nullptr; }
+            if (sl.d_chunk_counts[i]) { (void)hipFree(sl.d_chunk_counts[i]); sl.d_chunk_counts[i] = nullptr; }
+        }
+        if (sl.d_slot_L) { (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; }
+        if (sl.d_sample_slot) { (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr; }
+        if (sl.d_hits) { (void)hipFree(sl.d_hits); sl.d_hits = nullptr; }
+        if (sl.d_hit_prim) { (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr; }
+        sl.capacity = 0;
     }
-    if (d_slot_L_) { (void)hipFree(d_slot_L_); d_slot_L_ = nullptr; }
-    if (d_sample_slot_) { (void)hipFree(d_sample_slot_); d_sample_slot_ = nullptr; }
-    if (d_hits_) { (void)hipFree(d_hits_); d_hits_ = nullptr; }
-    if (d_hit_prim_) { (void)hipFree(d_hit_prim_); d_hit_prim_ = nullptr; }
-    pass_capacity_ = 0;
 }
 
-bool Renderer::ensure_pass_capacity(size_t nsamples)
+bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
 {
     alloc_failed_ = false;
-    if (nsamples <= pass_capacity_) return true;
-    HIP_TRY(hipStreamSynchronize(stream_));
-    free_pass_buffers();
+    if (nsamples <= sl.capacity) return true;
+    for (Slice& o : slices_) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
+    if (sl.capacity) {          // grow: release this slice's buffers only
+        for (int i = 0; i < 2; ++i) { (void)hipFree(sl.d_queue[i]); sl.d_queue[i] = nullptr; (void)hipFree(sl.d_chunk_counts[i]); sl.d_chunk_counts[i] = nullptr; }
+        (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr;
+        (void)hipFree(sl.d_hits); sl.d_hits = nullptr; (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr;
+        sl.capacity = 0;
+    }
     const size_t nchunks = (nsamples + chunk_ - 1) / chunk_;
     const size_t records = nchunks * chunk_ * records_per_sample_;
     // the kernels index hit records and light-term floats with 32 bits
@@ -347,25 +365,40 @@ bool Renderer::ensure_pass_capacity(size_t nsamples)
         last_error = "pass too large"; alloc_failed_ = true; return false;     // the caller retries with a smaller pass
     }
     for (int i = 0; i < 2; ++i) {
-        HIP_ALLOC(hipMalloc(&d_queue_[i], records * kRayRecordBytes));
-        HIP_ALLOC(hipMalloc((void**)&d_chunk_counts_[i], nchunks * 8));
+        HIP_ALLOC(hipMalloc(&sl.d_queue[i], records * kRayRecordBytes));
+        HIP_ALLOC(hipMalloc((void**)&sl.d_chunk_counts[i], nchunks * 8));
     }
-    HIP_ALLOC(hipMalloc(&d_hits_, records * 16));
-    HIP_ALLOC(hipMalloc((void**)&d_hit_prim_, records * 4));
-    HIP_ALLOC(hipMalloc((void**)&d_slot_L_, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
-    HIP_ALLOC(hipMalloc((void**)&d_sample_slot_, nchunks * chunk_ * 4));
-    pass_capacity_ = nsamples;
-    queue_records_ = records;
+    HIP_ALLOC(hipMalloc(&sl.d_hits, records * 16));
+    HIP_ALLOC(hipMalloc((void**)&sl.d_hit_prim, records * 4));
+    HIP_ALLOC(hipMalloc((void**)&sl.d_slot_L, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
+    HIP_ALLOC(hipMalloc((void**)&sl.d_sample_slot, nchunks * chunk_ * 4));
+    sl.capacity = nsamples;
+    sl.queue_records = records;
+    return true;
+}
+
+// Split the owned rows into `nslices` interleaved shares (blocks of stripe_rows rows, round-robin) and
+// upload each slice's row list.
+bool Renderer::assign_slice_rows(uint32_t nslices)
+{
+    if (rows_assigned_for_ == nslices) return true;
+    for (Slice& o : slices_) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
+    for (Slice& o : slices_) o.rows.clear();
+    for (size_t i = 0; i < owned_rows.size(); ++i) slices_[(i / cfg.stripe_rows) % nslices].rows.push_back(owned_rows[i]);
+    for (uint32_t s = 0; s < nslices; ++s)
+        if (!slices_[s].rows.empty()) HIP_TRY(hipMemcpy(slices_[s].d_rows, slices_[s].rows.data(), slices_[s].rows.size() * 4, hipMemcpyHostToDevice));
+    rows_assigned_for_ = nslices;
     return true;
 }
 
 // One wavefront pass: `nrows` rows starting at d_rows[row0], spp samples per pixel.
-bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample)
+bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample)
 {
     const uint32_t npix = explicit_sample ? 1u : nrows * cfg.width;
     const size_t nsamples = (size_t)npix * spp;
     if (nsamples == 0) return true;
-    if (!ensure_pass_capacity(nsamples)) return false;
+    if (!ensure_pass_capacity(sl, nsamples)) return false;
+    hipStream_t st = sl.stream;             // every launch of this pass goes to the slice's stream
     DPass ps{};
     ps.rows = d_rows; ps.row0 = row0; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
     ps.seed = (uint32_t)cfg.seed; ps.flags = cfg.flags; ps.recursions = cfg.recursions; ps.spread = cfg.spread;
@@ -373,7 +406,7 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
     ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
     ps.chunk = chunk_; ps.nchunks = (uint32_t)((nsamples + chunk_ - 1) / chunk_); ps.region = chunk_ * records_per_sample_;
-    ps.hit_prim = d_hit_prim_; ps.qstride = queue_records_;
+    ps.hit_prim = sl.d_hit_prim; ps.qstride = sl.queue_records;
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
     ps.refill_threshold = 16; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
@@ -385,7 +418,7 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
     const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
 
-    HIP_TRY(hipMemsetAsync(d_ctrl_, 0, kMaxRounds * kCtrlWordsPerRound * 4, stream_));
+    HIP_TRY(hipMemsetAsync(sl.d_ctrl, 0, kMaxRounds * kCtrlWordsPerRound * 4, st));
     // round r: trace the rays of level r (+ the shadow rays emitted by level r-1), then shade level r
     const uint32_t rounds = cfg.recursions + 2;
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -393,10 +426,10 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
             if (ev_used_ + 2 > ev_pool_.size()) {
                 for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); ev_pool_.push_back(ev); }
             }
-            HIP_TRY(hipEventRecord(ev_pool_[ev_used_], stream_));
+            HIP_TRY(hipEventRecord(ev_pool_[ev_used_], st));
         }
-        const void* in_q = r == 0 ? nullptr : d_queue_[(r - 1) & 1];
-        const void* in_c = r == 0 ? nullptr : d_chunk_counts_[(r - 1) & 1];
+        const void* in_q = r == 0 ? nullptr : sl.d_queue[(r - 1) & 1];
+        const void* in_c = r == 0 ? nullptr : sl.d_chunk_counts[(r - 1) & 1];
         const bool balance_dbg = count && getenv("MI355RT_DEBUG_UTIL") && !dscene_.oct_nodes;
         if (balance_dbg) {       // load-balance diagnostics of this launch (debug only: synchronises)
             DCounters init{};
@@ -405,23 +438,23 @@ bool Renderer::run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, u
             HIP_TRY(hipMemcpy(d_counters_, &init, sizeof init, hipMemcpyHostToDevice));
         }
         if (dscene_.oct_nodes)
-            HIP_TRY(launch_trace_octree(stream_, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, d_hits_, d_slot_L_, d_film_n_));
+            HIP_TRY(launch_trace_octree(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
         else
-            HIP_TRY(launch_trace(stream_, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, d_hits_, d_ctrl_ + r * kCtrlWordsPerRound, d_slot_L_, d_film_n_, d_counters_));
-        if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], stream_)); ev_used_ += 2; }
+            HIP_TRY(launch_trace(st, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
+        if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], st)); ev_used_ += 2; }
         ++launches_;
         if (balance_dbg) {
             DCounters c0{};
-            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(hipMemcpy(&c0, d_counters_, sizeof c0, hipMemcpyDeviceToHost));
             if (c0.n_waves)
                 fprintf(stderr, "[mi355rt] trace round %u: %llu waves, mean wave busy %.1f us, first wave out of work at %.1f us, last at %.1f us\n", r, c0.n_waves,
                         (double)c0.t_sum_end / c0.n_waves / 100.0, (double)(c0.t_first_end - c0.t_start) / 100.0, (double)(c0.t_last_end - c0.t_start) / 100.0);
         }
         if (r <= cfg.recursions)
-            HIP_TRY(launch_shade(stream_, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, d_hits_, d_queue_[r & 1], d_chunk_counts_[r & 1], d_slot_L_, d_sample_slot_, d_film_n_, d_counters_));
+            HIP_TRY(launch_shade(st, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, sl.d_hits, sl.d_queue[r & 1], sl.d_chunk_counts[r & 1], sl.d_slot_L, sl.d_sample_slot, d_film_n_, d_counters_));
     }
-    HIP_TRY(launch_resolve(stream_, ps, cfg.width, nlights_, d_slot_L_, d_sample_slot_, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
+    HIP_TRY(launch_resolve(st, ps, cfg.width, nlights_, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
     return true;
 }
 
@@ -431,11 +464,17 @@ bool Renderer::begin_call()
     ev_used_ = 0; launches_ = 0;
     HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
     HIP_TRY(hipEventRecord(ev_begin_, stream_));
+    active_slices_ = 1;
     return true;
 }
 
 bool Renderer::end_call(uint64_t primary)
 {
+    for (uint32_t i = 1; i < active_slices_; ++i) {          // join the slices on the main stream
+        HIP_TRY(hipEventRecord(slices_[i].done, slices_[i].stream));
+        HIP_TRY(hipStreamWaitEvent(stream_, slices_[i].done, 0));
+    }
+    active_slices_ = 1;
     HIP_TRY(hipEventRecord(ev_end_, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     DCounters shard[kShards], c{};
@@ -480,7 +519,7 @@ uint32_t Renderer::trace_frame_additive()
         while (end < rows.size() && std::find(rows.begin() + start, rows.begin() + end, rows[end]) == rows.begin() + end) ++end;
         if (hipMemcpyAsync(d_tmp_rows_, rows.data() + start, (end - start) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "row upload failed"; return 0; }
         if (hipStreamSynchronize(stream_) != hipSuccess) { last_error = "stream sync failed"; return 0; }
-        if (!run_pass(d_tmp_rows_, 0, (uint32_t)(end - start), 1, false, 0, 0)) return 0;
+        if (!run_pass(slices_[0], d_tmp_rows_, 0, (uint32_t)(end - start), 1, false, 0, 0)) return 0;
         start = end;
     }
     current_row = row;
@@ -493,26 +532,52 @@ bool Renderer::render(uint32_t spp)
     if (!begin_call()) return false;
     const uint32_t nrows = (uint32_t)owned_rows.size();
     if (nrows && spp) {
-        size_t target = cfg.samples_per_pass ? (size_t)cfg.samples_per_pass * cfg.width * nrows : ((size_t)32 << 20);
+        // concurrent frame slices: not worth their extra launches below ~1 Mi samples per slice
+        uint32_t nsl = std::max(1u, std::min(slices, kMaxSlices));
+        if (!slices_explicit) nsl = (uint32_t)std::min<uint64_t>(nsl, std::max<uint64_t>(1, (uint64_t)nrows * cfg.width * spp >> 20));
+        nsl = std::min(nsl, (nrows + cfg.stripe_rows - 1) / cfg.stripe_rows);
+        if (!assign_slice_rows(nsl)) return false;
+        size_t target = (size_t)32 << 20;                               // samples per pass of one slice
         if (const char* e = getenv("MI355RT_PASS_SAMPLES")) { long v = atol(e); if (v >= 1024) target = (size_t)v; }
         // The pass buffers (two ray queues, hit records, light terms: ~530 B per sample) are sized for the
         // largest pass.  If the device cannot hold them (another tenant, a 16 GB part), halve the pass and
         // try again; results do not depend on how samples are batched into passes.
+        struct PassDesc { uint32_t r0, nr, kk; };
+        std::vector<PassDesc> plan[kMaxSlices];
         for (;;) {
-            const uint32_t rows_per_pass = (uint32_t)std::min<size_t>(nrows, std::max<size_t>(1, target / cfg.width));
-            uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, target / ((size_t)rows_per_pass * cfg.width)));
-            if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
-            if (ensure_pass_capacity((size_t)rows_per_pass * cfg.width * std::min(k, spp))) {
-                for (uint32_t done = 0; done < spp; done += k) {
-                    const uint32_t kk = std::min(k, spp - done);
-                    for (uint32_t r0 = 0; r0 < nrows; r0 += rows_per_pass)
-                        if (!run_pass(d_owned_rows_, r0, std::min(rows_per_pass, nrows - r0), kk, false, 0, 0)) return false;
-                }
-                break;
+            bool ok = true;
+            for (uint32_t s = 0; s < nsl && ok; ++s) {
+                Slice& sl = slices_[s];
+                plan[s].clear();
+                const uint32_t snrows = (uint32_t)sl.rows.size();
+                if (!snrows) continue;
+                const size_t starget = cfg.samples_per_pass ? (size_t)cfg.samples_per_pass * cfg.width * snrows : target;
+                const uint32_t rows_per_pass = (uint32_t)std::min<size_t>(snrows, std::max<size_t>(1, starget / cfg.width));
+                uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, starget / ((size_t)rows_per_pass * cfg.width)));
+                if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
+                ok = ensure_pass_capacity(sl, (size_t)rows_per_pass * cfg.width * std::min(k, spp));
+                for (uint32_t done = 0; ok && done < spp; done += k)
+                    for (uint32_t r0 = 0; r0 < snrows; r0 += rows_per_pass)
+                        plan[s].push_back(PassDesc{ r0, std::min(rows_per_pass, snrows - r0), std::min(k, spp - done) });
             }
+            if (ok) break;
             if (!alloc_failed_ || cfg.samples_per_pass || target <= ((size_t)64 << 10)) return false;
             (void)hipGetLastError();
             target /= 2;
+        }
+        // fork: the other slices start after everything already queued on the main stream
+        for (uint32_t s = 1; s < nsl; ++s) HIP_TRY(hipStreamWaitEvent(slices_[s].stream, ev_begin_, 0));
+        active_slices_ = nsl;
+        // enqueue the passes round-robin so that no stream waits for the host
+        for (size_t p = 0;; ++p) {
+            bool any = false;
+            for (uint32_t s = 0; s < nsl; ++s) {
+                if (p >= plan[s].size()) continue;
+                any = true;
+                const PassDesc& d = plan[s][p];
+                if (!run_pass(slices_[s], slices_[s].d_rows, d.r0, d.nr, d.kk, false, 0, 0)) return false;
+            }
+            if (!any) break;
         }
     }
     return end_call((uint64_t)nrows * cfg.width * spp);
@@ -611,13 +676,13 @@ bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, fl
     if (nodes < nodes_per_sample || pixel >= cfg.width * cfg.height) { last_error = "bad debug_sample arguments"; return false; }
     HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
     ev_used_ = 0;
-    if (!run_pass(nullptr, 0, 1, 1, true, pixel, sampleno)) return false;
+    if (!run_pass(slices_[0], nullptr, 0, 1, 1, true, pixel, sampleno)) return false;
     HIP_TRY(hipStreamSynchronize(stream_));
     const uint32_t nl = std::max(nlights_, 1u);
     std::vector<float> raw((size_t)nodes_per_sample * nl * 3);
     uint32_t sl = 0xFFFFFFFFu;
-    HIP_TRY(hipMemcpy(&sl, d_sample_slot_, 4, hipMemcpyDeviceToHost));
-    if (sl != 0xFFFFFFFFu) HIP_TRY(hipMemcpy(raw.data(), d_slot_L_ + (size_t)sl * raw.size(), raw.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&sl, slices_[0].d_sample_slot, 4, hipMemcpyDeviceToHost));
+    if (sl != 0xFFFFFFFFu) HIP_TRY(hipMemcpy(raw.data(), slices_[0].d_slot_L + (size_t)sl * raw.size(), raw.size() * 4, hipMemcpyDeviceToHost));
     else std::fill(raw.begin(), raw.end(), 0.0f);
     HIP_TRY(hipMemcpy(color3, d_debug_color_, 12, hipMemcpyDeviceToHost));
     for (uint32_t nd = 0; nd < nodes_per_sample; ++nd) {

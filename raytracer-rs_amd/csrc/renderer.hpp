@@ -38,6 +38,8 @@ public:
     Bvh bvh;
     uint32_t ntri = 0;
     uint32_t current_row = 0;
+    uint32_t slices = 2;                  // concurrent frame slices of render() (1..8), MI355RT_SLICES / mi355rt_set_slices
+    bool slices_explicit = false;         // set through the API: used as given, also for small frames
     uint32_t nodes_per_sample = 1;
     uint32_t level_first[kMaxLevels + 1] = { 0 };
     std::vector<std::array<float, 6>> cull_boxes_;   // top BVH subtree boxes for primary-chunk culling
@@ -48,9 +50,29 @@ private:
     bool init(const SceneData& scene, std::string& err, int& code);
     bool bind();
     bool fail(hipError_t e, const char* what);
-    bool ensure_pass_capacity(size_t nsamples);
+    // A frame slice: an interleaved share of the owned rows with its own stream and pass buffers.  The
+    // slices of one render() call run concurrently, so that the drain window at the end of one slice's
+    // (persistent) trace launch is filled by the other slices' kernels.  Pixels of different slices are
+    // disjoint, so the film needs no ordering between them.
+    struct Slice {
+        hipStream_t stream = nullptr;            // slice 0 runs on the renderer's main stream
+        hipEvent_t done = nullptr;
+        std::vector<uint32_t> rows;              // this slice's rows (host copy of d_rows)
+        uint32_t* d_rows = nullptr;
+        uint32_t* d_ctrl = nullptr;              // per round: chunk cursors
+        void* d_queue[2] = { nullptr, nullptr };
+        uint32_t* d_chunk_counts[2] = { nullptr, nullptr };   // rays per chunk in each queue
+        void* d_hits = nullptr;
+        uint32_t* d_hit_prim = nullptr;          // hit records of the round being processed (16 B per queue record)
+        float* d_slot_L = nullptr;
+        uint32_t* d_sample_slot = nullptr;       // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
+        size_t capacity = 0;                     // samples
+        size_t queue_records = 0;
+    };
+    bool ensure_pass_capacity(Slice& sl, size_t nsamples);
     void free_pass_buffers();
-    bool run_pass(const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample);
+    bool assign_slice_rows(uint32_t nslices);
+    bool run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample);
     bool begin_call();
     bool end_call(uint64_t primary);
     DCamera device_camera() const;
@@ -69,20 +91,15 @@ private:
     uint32_t* d_owned_rows_ = nullptr; uint32_t* d_all_rows_ = nullptr; uint32_t* d_tmp_rows_ = nullptr;
     uint32_t* d_ldr_ = nullptr;
     DCounters* d_counters_ = nullptr;
-    uint32_t* d_ctrl_ = nullptr;         // [0..7] cursors, [8..15] queue counts
     float* d_debug_color_ = nullptr;
-    void* d_queue_[2] = { nullptr, nullptr };
-    uint32_t* d_chunk_counts_[2] = { nullptr, nullptr };   // rays per chunk in each queue
-    void* d_hits_ = nullptr;
-    uint32_t* d_hit_prim_ = nullptr;             // hit records of the round being processed (16 B per queue record)
+    static constexpr uint32_t kMaxSlices = 8;
+    Slice slices_[kMaxSlices];
+    uint32_t rows_assigned_for_ = 0;     // number of slices the row lists were last split into
+    uint32_t active_slices_ = 1;         // slices used by the call in flight (begin_call .. end_call)
     uint32_t chunk_ = 256;               // primary samples per work chunk
     uint32_t max_level_nodes_ = 1;
     uint32_t leaf_threshold_ = 16;
-    float* d_slot_L_ = nullptr;
-    uint32_t* d_sample_slot_ = nullptr;  // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
     bool alloc_failed_ = false;          // the last ensure_pass_capacity failure was an out-of-memory
-    size_t pass_capacity_ = 0;           // samples
-    size_t queue_records_ = 0;
     uint32_t records_per_sample_ = 1;
     uint32_t nlights_ = 0;
     uint64_t launches_ = 0;

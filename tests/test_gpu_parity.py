@@ -235,6 +235,36 @@ def test_stripes_partition_the_frame(pkg, scenes, oracle):
     assert np.array_equal(bits(acc), bits(fs))
 
 
+@pytest.mark.parametrize("slices", [1, 2, 3, 8])
+def test_concurrent_frame_slices_do_not_change_the_film(pkg, scenes, oracle, slices):
+    """render() splits its rows into concurrent slices (own stream + pass buffers each): the film, the ray
+    counts and repeated (accumulating) frames are identical to the oracle for every slice count, also when
+    the slices need several passes each and when they are combined with multi-GPU stripes."""
+    name, w, h, spp = "ico2", 72, 52, 3
+    orc = oracle.Oracle(scenes(name), w, h, seed=5, flags=oracle.FLAG_BRUTE_FORCE)
+    rt = make(pkg, scenes, name, w, h, seed=5, samples_per_pass=2)       # 2 passes per slice and frame
+    rt.set_slices(slices)
+    assert rt.get_slices() == slices
+    for frame in range(2):
+        counts = rt.render(spp)
+        oc = orc.render(spp, nthreads=8)
+        assert (counts.primary, counts.bounce, counts.shadow, counts.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+        gs, gq, gn = rt.film.pixel_datas()
+        os_, oq, on = orc.film()
+        assert np.array_equal(gn, on)
+        assert np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+    # stripes x slices: rank 1 of 2 owns every other block of 4 rows, split again into slices
+    part = make(pkg, scenes, name, w, h, seed=5, stripe_rows=4, stripe_rank=1, stripe_world=2)
+    part.set_slices(slices)
+    part.render(spp); part.render(spp)
+    ps, _, pn = part.film.pixel_datas()
+    rows = part.owned_rows()
+    assert np.array_equal(pn.reshape(h, w)[rows], on.reshape(h, w)[rows]) and pn.sum() == len(rows) * w * 2 * spp
+    assert np.array_equal(bits(ps).reshape(h, w, 3)[rows], bits(os_).reshape(h, w, 3)[rows])
+    with pytest.raises(Exception):
+        rt.set_slices(9)
+
+
 # ---- committed golden fixtures (tests/golden/make_golden.py) --------------------------------------------
 import os  # noqa: E402
 
