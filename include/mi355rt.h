@@ -165,7 +165,7 @@ int mi355rt_camera_get_ray(const mi355rt_handle* h, uint32_t u, uint32_t v, floa
 
 int mi355rt_set_seed(mi355rt_handle* h, uint64_t seed);
 int mi355rt_set_flags(mi355rt_handle* h, uint32_t flags);
-/* Number of concurrent frame slices mi355rt_render splits its rows into (1..8, default 2, or the
+/* Number of concurrent frame slices mi355rt_render splits its rows into (1..8, default 3, or the
  * environment variable MI355RT_SLICES).  Each slice runs its wavefront passes on its own HIP stream, so the
  * drain window of one slice's trace launch is filled by another slice's kernels; results do not depend on
  * it.  With MI355RT_FLAG_TIME_KERNELS the per-kernel times only mean something with 1 slice. */

@@ -537,7 +537,7 @@ bool Renderer::render(uint32_t spp)
         if (!slices_explicit) nsl = (uint32_t)std::min<uint64_t>(nsl, std::max<uint64_t>(1, (uint64_t)nrows * cfg.width * spp >> 20));
         nsl = std::min(nsl, (nrows + cfg.stripe_rows - 1) / cfg.stripe_rows);
         if (!assign_slice_rows(nsl)) return false;
-        size_t target = (size_t)32 << 20;                               // samples per pass of one slice
+        size_t target = (size_t)48 << 20;                               // samples per pass of one slice
         if (const char* e = getenv("MI355RT_PASS_SAMPLES")) { long v = atol(e); if (v >= 1024) target = (size_t)v; }
         // The pass buffers (two ray queues, hit records, light terms: ~530 B per sample) are sized for the
         // largest pass.  If the device cannot hold them (another tenant, a 16 GB part), halve the pass and
@@ -555,6 +555,7 @@ bool Renderer::render(uint32_t spp)
                 const uint32_t rows_per_pass = (uint32_t)std::min<size_t>(snrows, std::max<size_t>(1, starget / cfg.width));
                 uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, starget / ((size_t)rows_per_pass * cfg.width)));
                 if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
+                else { const uint32_t np = (spp + k - 1) / k; k = (spp + np - 1) / np; }     // equal passes: 48+16 -> 32+32
                 ok = ensure_pass_capacity(sl, (size_t)rows_per_pass * cfg.width * std::min(k, spp));
                 for (uint32_t done = 0; ok && done < spp; done += k)
                     for (uint32_t r0 = 0; r0 < snrows; r0 += rows_per_pass)
