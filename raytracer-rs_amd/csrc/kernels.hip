@@ -111,6 +111,26 @@ __device__ __forceinline__ f3 fetch_texel(const DScene& sc, uint32_t tex, float 
     return mk3(p[0], p[1], p[2]);
 }
 
+// Pass order of the pixels.  The rows of a pass are taken in groups of kRowGroup and walked column by column
+// inside a group, so that 64 consecutive samples are an 8x8 pixel tile and a chunk of 256 a 32x8 one: the
+// primary rays of a wave are as coherent as they can be, and the chunk culling below tests compact tiles.
+// (The film does not depend on the order: every pixel accumulates its own samples in sample order.)
+constexpr uint32_t kRowGroup = 8u;
+__device__ __forceinline__ void pass_column(const DPass& ps, uint32_t width, uint32_t p, uint32_t& first_row, uint32_t& nrows_in_group, uint32_t& x, uint32_t& y)
+{
+    const uint32_t gs = width * kRowGroup, g = p / gs, q = p - g * gs;
+    nrows_in_group = min(kRowGroup, ps.npix / width - g * kRowGroup);
+    x = nrows_in_group == kRowGroup ? q / kRowGroup : q / nrows_in_group;
+    y = q - x * nrows_in_group;
+    first_row = ps.row0 + g * kRowGroup;
+}
+__device__ __forceinline__ uint32_t pass_pixel(const DPass& ps, uint32_t width, uint32_t p)
+{
+    uint32_t first_row, nr, x, y;
+    pass_column(ps, width, p, first_row, nr, x, y);
+    return ps.rows[first_row + y] * width + x;
+}
+
 // pixel -> primary ray, mod.rs:93-96 + camera.rs:80-90.  gi = index of the primary sample in the pass.
 __device__ __forceinline__ void primary_sample(const DCamera& cam, const DPass& ps, const uint32_t* __restrict__ film_n, uint32_t gi,
                                                uint32_t& pixel, uint32_t& sampleno, f3& o, f3& d)
@@ -118,7 +138,7 @@ __device__ __forceinline__ void primary_sample(const DCamera& cam, const DPass& 
     if (ps.use_explicit) { pixel = ps.explicit_pixel; sampleno = ps.explicit_sampleno; }
     else {
         const uint32_t s = gi / ps.npix, p = gi - s * ps.npix;
-        pixel = ps.rows[ps.row0 + p / cam.width] * cam.width + p % cam.width;
+        pixel = pass_pixel(ps, cam.width, p);
         sampleno = film_n[pixel] + s;
     }
     uint32_t h0 = pixel, h1 = sampleno, h2 = 0u, h3 = ps.seed;
@@ -134,34 +154,33 @@ __device__ __forceinline__ void primary_sample(const DCamera& cam, const DPass& 
     o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
 }
 
-// Frustum culling of a whole chunk of primary samples.  The samples of a chunk are consecutive pixels
-// of (at most two) image rows at one sample index; their (dir_x, dir_y) of camera.rs:81-84 lie in a
-// rectangle whatever the jitter.  If that rectangle misses the screen-space bounds of every one of the
-// (up to 16) top BVH subtree boxes, no ray of the chunk can hit anything: all of them miss (mod.rs:99-100).  Purely
-// conservative: it only ever skips work whose outcome is "miss".
+// Frustum culling of a whole chunk of primary samples.  The samples of a chunk are a run of columns of one
+// row group at one sample index; their (dir_x, dir_y) of camera.rs:81-84 lie in a rectangle whatever the
+// jitter.  If that rectangle misses the screen-space bounds of every one of the (up to 16) top BVH subtree
+// boxes, no ray of the chunk can hit anything: all of them miss (mod.rs:99-100).  Purely conservative: it
+// only ever skips work whose outcome is "miss".
 __device__ __forceinline__ bool chunk_is_culled(const DCamera& cam, const DPass& ps, uint32_t chunk, uint32_t n)
 {
     if (!cam.cull_valid || ps.use_explicit || n == 0u) return false;
     const uint32_t g0 = chunk * ps.chunk, g1 = g0 + n - 1u;
     if (g0 / ps.npix != g1 / ps.npix) return false;                  // straddles two sample indices
-    const uint32_t p0 = g0 % ps.npix, p1 = g1 % ps.npix;
-    const uint32_t r0 = p0 / cam.width, r1 = p1 / cam.width;
-    if (r1 - r0 > 1u) return false;
-    for (uint32_t r = r0; r <= r1; ++r) {
-        const uint32_t xa = r == r0 ? p0 % cam.width : 0u, xb = r == r1 ? p1 % cam.width : cam.width - 1u;
-        const uint32_t row = ps.rows[ps.row0 + r];
-        const uint32_t ia = row * cam.width + xa, ib = row * cam.width + xb;
-        const uint32_t va = (ps.flags & 1u) ? ia / cam.width : ia / cam.height, vb = (ps.flags & 1u) ? ib / cam.width : ib / cam.height;
-        // same expressions as primary_sample with jitter 0 and 1 (monotonic in u, v), widened a little
-        const float x_lo = -cam.max_x + 2.0f * cam.max_x * ((float)xa / (float)cam.width);
-        const float x_hi = -cam.max_x + 2.0f * cam.max_x * (((float)xb + 1.0f) / (float)cam.width);
-        const float y_lo = -cam.max_y + 2.0f * cam.max_y * ((float)va / (float)cam.height);
-        const float y_hi = -cam.max_y + 2.0f * cam.max_y * (((float)vb + 1.0f) / (float)cam.height);
-        const float ex = 1e-5f * cam.max_x, ey = 1e-5f * cam.max_y;
-        for (uint32_t k = 0; k < cam.cull_valid; ++k) {
-            const bool outside = x_hi + ex < cam.cull_rect[k][0] || x_lo - ex > cam.cull_rect[k][1] || y_hi + ey < cam.cull_rect[k][2] || y_lo - ey > cam.cull_rect[k][3];
-            if (!outside) return false;
-        }
+    uint32_t fr0, nr0, xa, ya, fr1, nr1, xb, yb;
+    pass_column(ps, cam.width, g0 % ps.npix, fr0, nr0, xa, ya);
+    pass_column(ps, cam.width, g1 % ps.npix, fr1, nr1, xb, yb);
+    if (fr0 != fr1) return false;                                    // straddles two row groups
+    uint32_t row_lo = 0xFFFFFFFFu, row_hi = 0u;                      // all rows of the group (a superset of the chunk's)
+    for (uint32_t y = 0; y < nr0; ++y) { const uint32_t r = ps.rows[fr0 + y]; row_lo = min(row_lo, r); row_hi = max(row_hi, r); }
+    const uint32_t ia = row_lo * cam.width + xa, ib = row_hi * cam.width + xb;
+    const uint32_t va = (ps.flags & 1u) ? ia / cam.width : ia / cam.height, vb = (ps.flags & 1u) ? ib / cam.width : ib / cam.height;
+    // same expressions as primary_sample with jitter 0 and 1 (monotonic in u, v), widened a little
+    const float x_lo = -cam.max_x + 2.0f * cam.max_x * ((float)xa / (float)cam.width);
+    const float x_hi = -cam.max_x + 2.0f * cam.max_x * (((float)xb + 1.0f) / (float)cam.width);
+    const float y_lo = -cam.max_y + 2.0f * cam.max_y * ((float)va / (float)cam.height);
+    const float y_hi = -cam.max_y + 2.0f * cam.max_y * (((float)vb + 1.0f) / (float)cam.height);
+    const float ex = 1e-5f * cam.max_x, ey = 1e-5f * cam.max_y;
+    for (uint32_t k = 0; k < cam.cull_valid; ++k) {
+        const bool outside = x_hi + ex < cam.cull_rect[k][0] || x_lo - ex > cam.cull_rect[k][1] || y_hi + ey < cam.cull_rect[k][2] || y_lo - ey > cam.cull_rect[k][3];
+        if (!outside) return false;
     }
     return true;
 }
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= ps.npix) return;
     const uint32_t spp = ps.nsamples / ps.npix;
-    const uint32_t pixel = ps.use_explicit ? ps.explicit_pixel : ps.rows[ps.row0 + p / width] * width + p % width;
+    const uint32_t pixel = ps.use_explicit ? ps.explicit_pixel : pass_pixel(ps, width, p);
     f3 sum = mk3(0, 0, 0), sumsq = mk3(0, 0, 0);
     uint32_t n = 0;
     if (!ps.use_explicit) {
