@@ -211,18 +211,18 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
     bool exhausted = false;
     PullState w_pull;
     // lane state
-    bool busy = false;
     RayState rs;
     uint32_t rec = 0;                                // radiance: hit-record index; shadow: float index into slot_L (both < 2^32)
     // a shadow ray never touches rs.t / rs.u / rs.v (only radiance rays record a hit): they carry its light term
     ray_init(rs, mk3(0, 0, 0), mk3(0, 0, 1), false, sc.root);
+    rs.node = kNodeIdle;
 
     for (;;) {
         // ---- refill idle lanes from the current chunk (pull a new chunk when it runs dry)
         // A refill makes the wave wait for ray records that come from HBM, so it is done only when
         // at least ps.refill_threshold lanes are idle (or nothing is left to do): the other waves of
         // the SIMD then have enough work to cover the wait.
-        unsigned long long idle = __ballot(!busy);
+        unsigned long long idle = __ballot(rs.node == kNodeIdle);
         if ((uint32_t)__popcll(idle) < ps.refill_threshold && idle != ~0ull) idle = 0ull;
         while (idle != 0ull && !exhausted) {
             if (w_next >= w_ntot) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
             }
             const uint32_t avail = w_ntot - w_next;
             const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
-            if (!busy && rank < avail) {
+            if (rs.node == kNodeIdle && rank < avail) {
                 const uint32_t i = w_next + rank;
                 f3 o, d;
                 bool shadow = false;
@@ -263,40 +263,31 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
                 }
                 ray_init(rs, o, d, shadow, sc.root);
                 if (shadow) { rs.t = sh_L4.x; rs.u = sh_L4.y; rs.v = sh_L4.z; }
-                busy = true;
             }
             w_next += min((uint32_t)__popcll(idle), avail);
-            idle = __ballot(!busy);
+            idle = __ballot(rs.node == kNodeIdle);
         }
-        if (__ballot(busy) == 0ull) break;
+        if (__ballot(rs.node != kNodeIdle) == 0ull) break;
 
         // ---- while-while scheduling: inner-node steps run for the lanes at inner nodes; lanes that
         // reached a leaf wait until enough of them are there (or nobody is left at an inner node),
-        // so that the expensive triangle code always runs with a well-filled wave.  The two sections
-        // are entered on wave-uniform conditions; inside, lanes are predicated, not branched.
-        bool need_pop = false, fin = false;
-        // extra inner steps (+ pop) before the scheduling decisions below: amortises their cost
+        // so that the expensive triangle code always runs with a well-filled wave.  The sections are
+        // entered on wave-uniform conditions; inside, lanes are predicated, not branched, and every
+        // section pops (or finishes) its own lanes, so a lane that leaves a node is busy again at once.
 #pragma unroll
-        for (int u = 1; u < kInnerStepsPerIteration; ++u) {
-            const bool at0 = busy & !fin & (rs.node >= 0);
-            if (__ballot(at0) == 0ull) break;
-            inner_pred<COUNT>(sc, rs, at0, stack, kBlock, (int)ps.stack_depth, need_pop, acc_nodes);
+        for (int u = 0; u < kInnerStepsPerIteration; ++u) {
+            if (__ballot(lane_at_inner(rs)) == 0ull) break;
+            inner_pred<COUNT>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_nodes);
             if (COUNT) ++acc_ie;
-            pop_pred(rs, need_pop, stack, kBlock, (int)ps.stack_depth, fin);
-            need_pop = false;
         }
-        const bool at_inner = busy & !fin & (rs.node >= 0);
-        const unsigned long long m_inner = __ballot(at_inner);
-        if (m_inner != 0ull) { inner_pred<COUNT>(sc, rs, at_inner, stack, kBlock, (int)ps.stack_depth, need_pop, acc_nodes); if (COUNT) ++acc_ie; }
-        const bool at_leaf = busy & !fin & !need_pop & (rs.node < 0);
-        const unsigned long long m_leaf = __ballot(at_leaf);
-        if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(busy & !fin & !need_pop & (rs.node >= 0)) == 0ull))
-            { leaf_pred<COUNT>(sc, rs, at_leaf, need_pop, fin, acc_tris); if (COUNT) ++acc_le; }
-        pop_pred(rs, need_pop, stack, kBlock, (int)ps.stack_depth, fin);
+        const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
+        if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
+            { leaf_pred<COUNT>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_tris); if (COUNT) ++acc_le; }
+        const bool fin = rs.node == kNodeFin;
         if (__ballot(fin) != 0ull) {
             if (fin) {
-                busy = false;
-                if (!rs.shadow) {
+                rs.node = kNodeIdle;
+                if (rs.occ < 0) {                                               // radiance ray
                     ps.hit_prim[rec] = rs.prim;                                 // 4 B for every ray, the 16 B record only for hits
                     if (rs.prim != kMiss) hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
                 } else if (rs.occ != 1) {                              // not blocked, mod.rs:232

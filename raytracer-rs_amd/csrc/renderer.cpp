@@ -68,7 +68,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (scene.tri_geom.size() * 9 != scene.tri_verts.size()) { err = "tri_verts / tri_geom size mismatch"; return false; }
     for (uint32_t g : scene.tri_geom) if (g >= scene.materials.size()) { err = "tri_geom entry out of range"; return false; }
     for (auto& m : scene.materials) if (m.kind == 1 && m.tex_id >= scene.textures.size()) { err = "material texture id out of range"; return false; }
-    if (scene.tri_geom.size() >= (1u << 28)) { err = "too many triangles"; return false; }
+    if (scene.tri_geom.size() >= (1u << 26)) { err = "too many triangles"; return false; }     // 32-bit byte offsets into the 48-byte triangle array
     {   // radiance tree: level l has prod_{j<l} spread*(recursions-j) nodes
         uint64_t count = 1, first = 0;
         for (uint32_t l = 0; l <= cfg.recursions; ++l) {

@@ -25,7 +25,7 @@ struct RayState {
     int node;              // >= 0 inner node, < 0 leaf code
     uint32_t tri;          // next triangle of the current leaf
     int sp;
-    int occ;               // shadow rays: 0 nothing, 1 blocked, 2 unblocked by a hit at t <= 0.01
+    int occ;               // shadow rays: 0 nothing, 1 blocked, 2 unblocked by a hit at t <= 0.01; radiance rays: -1
     bool shadow;
 };
 
@@ -48,7 +48,7 @@ __device__ __forceinline__ void ray_init(RayState& s, f3 o, f3 d, bool shadow, i
     s.selz = __builtin_signbitf(bz) ? 0x01000302u : 0x03020100u;
     s.tlimit = shadow ? 0x1.fffffep-1f : __builtin_inff();     // shadow: t < 1.0
     s.t = __builtin_inff(); s.u = 0.0f; s.v = 0.0f; s.prim = 0xFFFFFFFFu;
-    s.node = root; s.tri = 0u; s.sp = 0; s.occ = 0; s.shadow = shadow;
+    s.node = root; s.tri = 0u; s.sp = 0; s.occ = shadow ? 0 : -1; s.shadow = shadow;
 }
 
 // Slab test of one child box of a 32-byte node (bvh.hpp).  Per axis the two half-precision bounds sit
@@ -160,17 +160,40 @@ __device__ __forceinline__ void ray_run(const DScene& sc, RayState& s, int* stac
 
 // ---- predicated steps for the persistent trace kernel ------------------------------------------------------
 // Same arithmetic as inner_step / leaf_step, written WITHOUT per-lane branches: every lane of the wave
-// runs the code, `pred` says whether the lane takes part, state changes are selects, LDS pushes of lanes
-// that do not push go to a trash row.  Divergent branches cost this kernel more scalar exec-mask
-// bookkeeping than the arithmetic they skip (profiles/r01_notes.md).
-template <bool COUNT>
-__device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, bool pred, int* stack, int stride, int trash_row,
-                                           bool& need_pop, uint32_t& n_nodes)
+// runs the code, state changes are selects, LDS accesses of lanes that neither push nor pop go to a trash
+// row.  Divergent branches cost this kernel more scalar exec-mask bookkeeping than the arithmetic they
+// skip (profiles/r01_notes.md).
+//
+// The whole lane state machine lives in s.node, so that every predicate is ONE compare on a VGPR (a lane
+// mask in SGPRs) instead of a boolean carried through the loop in a VGPR:
+//   node >= 0                   at an inner node
+//   kNodeFin < node < 0         at a leaf: ~node = first_triangle << 3 | (triangles left - 1); stepping to
+//                               the next triangle of the leaf is code += 7, i.e. node -= 7
+//   node == kNodeFin            the ray is finished, its result is not written yet
+//   node == kNodeIdle           the lane holds no ray
+// (triangle counts are < 2^26, so no leaf code collides with the two sentinels.)  s.occ < 0 marks a
+// radiance ray; s.tri and s.shadow are not used on this path.
+constexpr int kNodeIdle = (int)0x80000000u, kNodeFin = (int)0x80000001u;
+__device__ __forceinline__ bool lane_at_inner(const RayState& s) { return s.node >= 0; }
+__device__ __forceinline__ bool lane_at_leaf(const RayState& s) { return (uint32_t)s.node > 0x80000001u; }
+
+// pop for the lanes in `want`: next deferred node, or kNodeFin when the stack is empty
+__device__ __forceinline__ int pop_or_finish(RayState& s, bool want, const int* stack, int stride, int trash_row)
 {
-    const uint4* __restrict__ nodes = (const uint4*)sc.nodes;
+    const bool take = want & (s.sp > 0);
+    const int popped = stack[(take ? s.sp - 1 : trash_row) * stride];
+    s.sp -= take ? 1 : 0;
+    return take ? popped : kNodeFin;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* stack, int stride, int trash_row, uint32_t& n_nodes)
+{
+    const bool pred = s.node >= 0;
     if (COUNT) n_nodes += pred ? 1u : 0u;
-    const int ni = pred ? s.node : 0;
-    const uint4 q0 = nodes[2 * ni], q1 = nodes[2 * ni + 1];
+    const uint32_t off = pred ? (uint32_t)s.node << 5 : 0u;           // 32-byte nodes, unsigned 32-bit byte offset
+    const char* __restrict__ base = (const char*)sc.nodes;
+    const uint4 q0 = *(const uint4*)(base + off), q1 = *(const uint4*)(base + off + 16u);
     float tn0, tf0, tn1, tf1;
     slab_child(q0, s, tn0, tf0);
     slab_child(q1, s, tn1, tf1);
@@ -181,23 +204,22 @@ __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, bool p
     const bool take1 = h1 & (!h0 | sw);
     const int near_c = take1 ? c1i : c0i, far_c = take1 ? c0i : c1i;
     const bool push = pred & h0 & h1;
+    const bool none = pred & !(h0 | h1);
     stack[(push ? s.sp : trash_row) * stride] = far_c;
     s.sp += push ? 1 : 0;
-    const bool any = h0 | h1;
-    s.node = (pred & any) ? near_c : s.node;
-    s.tri = pred ? 0u : s.tri;
-    need_pop = need_pop | (pred & !any);
+    const int next = pop_or_finish(s, none, stack, stride, trash_row);
+    s.node = pred ? (none ? next : near_c) : s.node;
 }
 
 template <bool COUNT>
-__device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, bool pred, bool& need_pop, bool& fin, uint32_t& n_tris)
+__device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const int* stack, int stride, int trash_row, uint32_t& n_tris)
 {
-    const float4* __restrict__ tris = (const float4*)sc.tris;
+    const bool pred = lane_at_leaf(s);
     const uint32_t code = ~(uint32_t)s.node;
-    const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
     if (COUNT) n_tris += pred ? 1u : 0u;
-    const uint32_t ti = pred ? first + s.tri : 0u;
-    const float4 t0 = tris[3 * ti], t1 = tris[3 * ti + 1], t2 = tris[3 * ti + 2];
+    const uint32_t off = pred ? (code >> 3) * 48u : 0u;              // 48-byte triangles, unsigned 32-bit byte offset
+    const char* __restrict__ base = (const char*)sc.tris;
+    const float4 t0 = *(const float4*)(base + off), t1 = *(const float4*)(base + off + 16u), t2 = *(const float4*)(base + off + 32u);
     // Moller-Trumbore "late out", intersect.rs:62-98, same operation order
     const f3 v0 = mk3(t0.x, t0.y, t0.z), v0v1 = mk3(t1.x, t1.y, t1.z), v0v2 = mk3(t2.x, t2.y, t2.z);
     const f3 pvec = cross3(s.d, v0v2);
@@ -210,25 +232,16 @@ __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, bool pr
     const float t = dot3(v0v2, qvec) * inv_det;
     const bool ok = pred & !(fabsf(det) < 1.1920929e-7f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(t < 0.0f);
     const uint32_t prim = __float_as_uint(t0.w);
-    const bool better = ok & !s.shadow & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
+    const bool is_shadow = s.occ >= 0;
+    const bool better = ok & !is_shadow & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
     s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
-    const bool sh = ok & s.shadow & (t <= s.tlimit);
+    const bool sh = ok & is_shadow & (t <= s.tlimit);
     const bool sh_far = sh & (t > 0.01f), sh_near = sh & !(t > 0.01f);
     s.tlimit = better ? t : (sh_far ? 0.01f : s.tlimit);
     s.occ = sh_near ? 2 : (sh_far ? 1 : s.occ);
-    fin = fin | sh_near;
-    s.tri += pred ? 1u : 0u;
-    need_pop = need_pop | (pred & !sh_near & (s.tri >= cnt));
-}
-
-__device__ __forceinline__ void pop_pred(RayState& s, bool need_pop, const int* stack, int stride, int trash_row, bool& fin)
-{
-    const bool take = need_pop & (s.sp > 0);
-    const int popped = stack[(take ? s.sp - 1 : trash_row) * stride];
-    fin = fin | (need_pop & (s.sp == 0));
-    s.sp -= take ? 1 : 0;
-    s.node = take ? popped : s.node;
-    s.tri = need_pop ? 0u : s.tri;
+    const bool last = (code & 7u) == 0u;
+    const int next = pop_or_finish(s, pred & last & !sh_near, stack, stride, trash_row);
+    s.node = pred ? (sh_near ? kNodeFin : (last ? next : s.node - 7)) : s.node;
 }
 
 // ---- reference-exact intersector (MI355RT_FLAG_OCTREE_SEMANTICS) ---------------------------------------
