@@ -409,7 +409,7 @@ bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32
     ps.hit_prim = sl.d_hit_prim; ps.qstride = sl.queue_records;
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
-    ps.refill_threshold = 16; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
+    ps.refill_threshold = 24; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
     ps.pull_mode = 4u;                  // 8 interleaved cursors (see pull_chunk in kernels.hip)
     if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
     ps.pull_group = 1; if (const char* e = getenv("MI355RT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.pull_group = (uint32_t)v; }
