@@ -194,7 +194,7 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
 
 // ---- trace: closest hit of every ray of a round --------------------------------------------------
 template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam, DPass ps,
+__global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       float4* __restrict__ hits, uint32_t* cursor,
                                                       float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
@@ -229,13 +229,15 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
                 uint32_t c = 0u;
                 c = w_chunk;
                 if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c)) { exhausted = true; break; }
-                w_chunk = c; w_next = 0u;
+                // bcast_first: these are wave-uniform by construction; saying so keeps them in SGPRs
+                w_chunk = bcast_first(c); w_next = 0u;
                 if (PRIMARY) {
-                    w_nrad = min(ps.chunk, ps.nsamples - c * ps.chunk);
-                    if (chunk_is_culled(cam, ps, c, w_nrad)) w_nrad = 0u;    // the shade kernel makes the same decision
+                    w_nrad = min(ps.chunk, ps.nsamples - w_chunk * ps.chunk);
+                    if (chunk_is_culled(cam, ps, w_chunk, w_nrad)) w_nrad = 0u;    // the shade kernel makes the same decision
+                    w_nrad = bcast_first(w_nrad);
                     w_ntot = w_nrad;
                 }
-                else { const uint2 n = in_counts[c]; w_nrad = n.x; w_ntot = n.x + n.y; }
+                else { const uint2 n = in_counts[w_chunk]; w_nrad = bcast_first(n.x); w_ntot = w_nrad + bcast_first(n.y); }
                 continue;
             }
             const uint32_t avail = w_ntot - w_next;
@@ -250,15 +252,19 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
                     primary_sample(cam, ps, film_n, w_chunk * ps.chunk + i, pixel, sampleno, o, d);
                     rec = w_chunk * ps.region + i;
                 } else {
-                    const size_t r = record_index(ps, w_chunk, i, w_nrad);
-                    const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
-                    o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+                    // record index and byte offsets in 32 bits (records * 16 < 2^32: renderer.cpp); the three
+                    // planes of the queue are wave-uniform base pointers
                     shadow = i >= w_nrad;
-                    rec = (uint32_t)r;
+                    const uint32_t r = w_chunk * ps.region + (shadow ? ps.region - 1u - (i - w_nrad) : i);
+                    const char* __restrict__ p0 = (const char*)in_q;
+                    const char* __restrict__ p1 = (const char*)(in_q + ps.qstride);
+                    const float4 r0 = *(const float4*)(p0 + (r << 4)), r1 = *(const float4*)(p1 + (r << 4));
+                    o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+                    rec = r;
                     if (shadow) {       // keep what the finish needs in registers: no load when the ray ends
-                        sh_L4 = in_q[2 * ps.qstride + r];
-                        const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
-                        rec = 3u * ((slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
+                        const char* __restrict__ p2 = (const char*)(in_q + 2 * ps.qstride);
+                        sh_L4 = *(const float4*)(p2 + (r << 4));
+                        rec = __float_as_uint(r1.z);           // float index of its light term in slot_L (shade kernel)
                     }
                 }
                 ray_init(rs, o, d, shadow, sc.root);
@@ -288,8 +294,8 @@ __global__ __launch_bounds__(kBlock, 7) void trace_kernel(DScene sc, DCamera cam
             if (fin) {
                 rs.node = kNodeIdle;
                 if (rs.occ < 0) {                                               // radiance ray
-                    ps.hit_prim[rec] = rs.prim;                                 // 4 B for every ray, the 16 B record only for hits
-                    if (rs.prim != kMiss) hits[rec] = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
+                    *(uint32_t*)((char*)ps.hit_prim + (rec << 2)) = rs.prim;     // 4 B for every ray, the 16 B record only for hits
+                    if (rs.prim != kMiss) *(float4*)((char*)hits + (rec << 4)) = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
                 } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
                     float* dst = slot_L + rec;
                     dst[0] = rs.t; dst[1] = rs.u; dst[2] = rs.v;
@@ -343,8 +349,7 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
                 if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
             } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {          // not blocked, mod.rs:226-232
                 const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
-                const uint32_t slot = __float_as_uint(r1.z), meta = __float_as_uint(r1.w);
-                float* dst = slot_L + 3ull * (((size_t)slot * ps.nodes_per_sample + ((meta >> 8) & 0xFFFFu)) * sc.nlights + (meta >> 24));
+                float* dst = slot_L + __float_as_uint(r1.z);
                 dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
             }
         }
@@ -450,7 +455,8 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene s
                 if (want && out_front + oi < ps.region) {
                     const size_t r = base + (ps.region - 1u - oi);
                     out_q[r] = make_float4(so.x, so.y, so.z, sd.x);
-                    out_q[ps.qstride + r] = make_float4(sd.y, sd.z, __uint_as_float(slot), __uint_as_float(1u | (level << 4) | (node << 8) | (li << 24)));
+                    const uint32_t term = 3u * ((slot * ps.nodes_per_sample + node) * sc.nlights + li);    // float index in slot_L (< 2^32: renderer.cpp)
+                    out_q[ps.qstride + r] = make_float4(sd.y, sd.z, __uint_as_float(term), 0.0f);
                     out_q[2 * ps.qstride + r] = make_float4(c.x, c.y, c.z, 0.0f);
                 }
             }

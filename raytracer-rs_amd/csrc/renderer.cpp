@@ -360,8 +360,8 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
     }
     const size_t nchunks = (nsamples + chunk_ - 1) / chunk_;
     const size_t records = nchunks * chunk_ * records_per_sample_;
-    // the kernels index hit records and light-term floats with 32 bits
-    if (nsamples > 0x7FFFFFFFull || records > 0xFFFFFFFFull || nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 3ull > 0xFFFFFFFFull) {
+    // the kernels index light-term floats with 32 bits and address hit / ray records with 32-bit BYTE offsets (16 B each)
+    if (nsamples > 0x7FFFFFFFull || records > 0x0FFFFFFFull || nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 3ull > 0xFFFFFFFFull) {
         last_error = "pass too large"; alloc_failed_ = true; return false;     // the caller retries with a smaller pass
     }
     for (int i = 0; i < 2; ++i) {
