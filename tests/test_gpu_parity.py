@@ -421,3 +421,69 @@ def test_tiny_and_odd_image_sizes(pkg, oracle, scenes):
         assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0])), (w, h)
         assert rt.trace_frame_additive() == orc.trace_frame_additive() == 50 * w
         assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0])), (w, h)
+
+
+def test_4k_frame_tiled_over_8_stripes_matches_oracle_on_sampled_rows(pkg, scenes, oracle):
+    """BASELINE config 5 in small: thai2 3840x2160 dealt to 8 ranks in stripes of 8 rows; two of the ranks
+    are rendered (2 spp) and rows picked from their stripes are bit-identical to the oracle rendering just
+    those rows; rows of other ranks stay untouched."""
+    w, h, spp = 3840, 2160, 2
+    orc = oracle.Oracle(scenes("thai2"), w, h, seed=1, flags=oracle.FLAG_BRUTE_FORCE)
+    for rank, rows in ((3, (24, 1051)), (6, (1584, 2096))):
+        rt = make(pkg, scenes, "thai2", w, h, seed=1, stripe_rows=8, stripe_rank=rank, stripe_world=8)
+        c = rt.render(spp)
+        owned = rt.owned_rows()
+        assert owned.size == (272 if rank < 6 else 264) and np.all((owned // 8) % 8 == rank)    # 270 blocks of 8 rows over 8 ranks
+        assert c.primary == owned.size * w * spp
+        s_, _, n = rt.film.pixel_datas()
+        n = n.reshape(h, w)
+        assert np.all(n[owned] == spp) and n.sum() == owned.size * w * spp
+        for r0 in rows:
+            assert (r0 // 8) % 8 == rank
+            orc.render(spp, nthreads=16, rows=(r0, r0 + 1))
+            os_, _, _ = orc.film()
+            assert np.array_equal(bits(s_).reshape(h, w, 3)[r0], bits(os_).reshape(h, w, 3)[r0])
+
+
+def _random_scene(scenes, ntri, seed):
+    """ntri small random triangles in a slab in front of the 4boxes camera (materials / light from 4boxes)."""
+    rng = np.random.default_rng(seed)
+    sc = dict(scenes("4boxes"))
+    lo, hi = sc["tri_verts"].reshape(-1, 3).min(0), sc["tri_verts"].reshape(-1, 3).max(0)
+    centre = rng.uniform(lo, hi, size=(ntri, 1, 3))
+    # strongly non-uniform: half of the triangles crowd into 2 % of the volume, so the SAH tree gets deep
+    crowd = rng.random(ntri) < 0.5
+    centre[crowd] = lo + (hi - lo) * (0.49 + 0.02 * rng.random((int(crowd.sum()), 1, 3)))
+    size = np.where(crowd, 0.002, 0.05)[:, None, None] * (hi - lo).max()
+    sc["tri_verts"] = (centre + rng.uniform(-1.0, 1.0, size=(ntri, 3, 3)) * size).astype(np.float32).reshape(ntri, 9)
+    sc["tri_geom"] = rng.integers(0, len(sc["mat_kind"]), size=ntri).astype(np.uint32)
+    return sc
+
+
+def test_large_random_scene_deep_tree(pkg, scenes, oracle):
+    """120 000 random triangles, half of them crowded into a tiny volume: a deep, unbalanced BVH (more stack
+    rows than 8 blocks per CU leave room for).  Closest hits of random rays and a small rendered frame are
+    bit-identical to the brute-force oracle."""
+    sc = _random_scene(scenes, 120000, 7)
+    w, h, spp = 40, 24, 2
+    rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=11)
+    st = rt.accel_stats()
+    assert st["max_depth"] > 18 and st["max_leaf"] <= 4 and st["leaves"] >= 30000
+    rng = np.random.default_rng(3)
+    n = 6000
+    lo, hi = sc["tri_verts"].reshape(-1, 3).min(0), sc["tri_verts"].reshape(-1, 3).max(0)
+    rays = np.empty((n, 6), np.float32)
+    rays[:, :3] = rng.uniform(lo - 1.0, hi + 1.0, size=(n, 3))
+    tgt = rng.uniform(lo, hi, size=(n, 3)); tgt[::2] = lo + (hi - lo) * (0.49 + 0.02 * rng.random((n // 2, 3)))
+    rays[:, 3:] = tgt - rays[:, :3]
+    tuv, prim = rt.intersect_rays(rays)
+    otuv, oprim = oracle.Oracle(sc, w, h, seed=11, flags=oracle.FLAG_BRUTE_FORCE).intersect(rays, brute=True, nthreads=16)
+    assert np.array_equal(prim, oprim) and (prim != 0xFFFFFFFF).mean() > 0.3
+    hit = prim != 0xFFFFFFFF
+    assert np.array_equal(bits(tuv[hit]), bits(otuv[hit]))
+    orc = oracle.Oracle(sc, w, h, seed=11, flags=oracle.FLAG_BRUTE_FORCE)
+    c = rt.render(spp); oc = orc.render(spp, nthreads=16)
+    assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+    assert c.primary_hits > 0
+    gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+    assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
