@@ -175,7 +175,9 @@ def main():
                          "whole_frame_logical_gbs": round(total_rays * bytes_per_ray / elapsed / 1e9, 1),
                          "kernel": "trace_kernel", "launches": int(launches), "avg_launch_ms": round(trace_ms / max(launches, 1), 4),
                          "bytes_per_ray": round(bytes_per_ray, 1), "node_bytes": node_bytes, "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
-                         "note": "logical bytes (SURVEY.md 8d); the 1.5 MB scene is cache-resident, measured HBM traffic is queues + film only"},
+                         "valu_issue_frac": valu_issue_fraction(),
+                         "note": "logical bytes (SURVEY.md 8d); the 1.5 MB scene is cache-resident, measured HBM traffic is queues + film only; "
+                                 "the kernel is bound by VALU issue (valu_issue_frac, offline SQ counters in profiles/r01_pmc_sq_summary_final.txt)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ge, scene)
@@ -206,6 +208,28 @@ def pmc_traffic_per_launch():
             vals[name] = float(v) * 1024.0 / n
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+    return None
+
+
+def valu_issue_fraction():
+    """Fraction of the time the vector ALUs of the secondary trace launches issue an instruction, from the
+    committed rocprofv3 SQ counter passes (profiles/r01_pmc_sq_summary_final.txt): SQ_INSTS_VALU / 1024 SIMDs
+    x 4 cycles per wave64 instruction over SQ_BUSY_CYCLES / 32 shader engines.  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sq_summary_final.txt")
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    vals = {}
+    take = False
+    for line in lines:
+        if not line.startswith(" "):
+            take = line.startswith("S:trace_kernel<false, fals")
+        elif take:
+            name, v = line.split()
+            vals.setdefault(name, float(v))
+    if "SQ_INSTS_VALU" in vals and vals.get("SQ_BUSY_CYCLES"):
+        return round(vals["SQ_INSTS_VALU"] / 1024.0 * 4.0 / (vals["SQ_BUSY_CYCLES"] / 32.0), 3)
     return None
 
 
