@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--scene", default=SCENE)
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fix-row-index", action="store_true",
+                    help="v = idx / width instead of the reference's idx / height (SURVEY.md 8d: reported next to the headline, never as it)")
     ap.add_argument("--slices", type=int, default=0, help="concurrent frame slices of the timed frames (0: library default)")
     args = ap.parse_args()
 
@@ -77,6 +79,8 @@ def main():
     rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, WIDTH, HEIGHT, seed=1, device=local_rank,
                                           stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_world=world,
                                           flags=0)
+    base_flags = pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0
+    rt.set_flags(base_flags)
     if args.slices:
         rt.set_slices(args.slices)
     slices = rt.get_slices()
@@ -99,12 +103,12 @@ def main():
         return counts
 
     # instrumented frame (untimed): BVH nodes visited / triangles tested per ray for the roofline figure
-    rt.set_flags(pkg.FLAG_COUNT_STEPS)
+    rt.set_flags(base_flags | pkg.FLAG_COUNT_STEPS)
     rt.film.clear()
     c = rt.render(max(1, min(4, spp)))
     nodes_per_ray = c.nodes_visited / max(1, c.primary + c.bounce + c.shadow)
     tris_per_ray = c.tris_tested / max(1, c.primary + c.bounce + c.shadow)
-    rt.set_flags(0)
+    rt.set_flags(base_flags)
 
     for _ in range(args.warmup):
         step()
@@ -121,7 +125,7 @@ def main():
     # trace launch (on the stream it is launched on).  The frames above run several slices concurrently:
     # their kernels share the chip and have no individual duration, so the per-launch time is taken here.
     rt.set_slices(1)
-    rt.set_flags(pkg.FLAG_TIME_KERNELS)
+    rt.set_flags(base_flags | pkg.FLAG_TIME_KERNELS)
     step()
     ksteps = max(1, min(args.steps, 3))
     sync()
@@ -159,8 +163,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s 1920x1080, %d spp per GPU (frame = %d spp), recursions 2 / spread 1, reference pixel mapping, "
-                                   "rows dealt in stripes of %d" % (args.scene, args.spp, spp, STRIPE_ROWS),
+            "config": {"workload": "%s 1920x1080, %d spp per GPU (frame = %d spp), recursions 2 / spread 1, %s, "
+                                   "rows dealt in stripes of %d" % (args.scene, args.spp, spp, "row index FIXED (v = idx / width)" if args.fix_row_index else "reference pixel mapping", STRIPE_ROWS),
                        "scene": args.scene, "width": WIDTH, "height": HEIGHT, "spp_per_gpu": args.spp, "seed": 1,
                        "slices": slices, "parallelism": "row stripes x%d, RCCL all_gather of u32 stripes" % world},
             "primary_mrays_per_s": round(primary / elapsed / 1e6, 2),
@@ -180,7 +184,7 @@ def main():
                                  "the kernel is bound by VALU issue (valu_issue_frac, offline SQ counters in profiles/r01_pmc_sq_summary_final.txt)"},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ge, scene)
+            out["cpu_baseline"] = cpu_baseline(ge, scene, args.fix_row_index)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -233,11 +237,11 @@ def valu_issue_fraction():
     return None
 
 
-def cpu_baseline(ge, scene):
+def cpu_baseline(ge, scene, fix_row_index=False):
     """The oracle (oracle/oracle.c) on this box's host cores, bounded sample of the same workload."""
     O = ge.load_oracle()
     ncores = min(os.cpu_count() or 1, 64)
-    orc = O.Oracle(scene, WIDTH, HEIGHT, seed=1)
+    orc = O.Oracle(scene, WIDTH, HEIGHT, seed=1, flags=O.FLAG_FIX_ROW_INDEX if fix_row_index else 0)
     # whole 1920x1080 frames at 1 spp, repeated until ~12 s of wall time have been spent
     t0 = time.perf_counter()
     tot = dict(primary=0, bounce=0, shadow=0)

@@ -10,3 +10,4 @@ timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_wri
 timeout -k 10 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_l2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --slices 1 > /dev/null 2>&1; echo "l2 done"
 python bench.py --steps 5 --warmup 2 > $out/bench.json 2>/dev/null; cut -c1-200 $out/bench.json
 for s in ico2 4boxes; do python bench.py --steps 3 --warmup 1 --no-cpu-baseline --scene $s > $out/bench_$s.json 2>/dev/null; done
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fix-row-index > $out/bench_fix_row_index.json 2>/dev/null
