@@ -527,12 +527,20 @@ __device__ f3 node_radiance(const float* __restrict__ L, const DPass& ps, uint32
     }
 }
 
+// kResolveLanes consecutive lanes work on one pixel: lane j evaluates the radiance trees of samples j,
+// j + kResolveLanes, ... (the loads), then the values of one round are exchanged inside the wave and every
+// lane of the group ADDS them in sample order (bit-exactness) — redundantly, so there is no divergence.
+// With one thread per pixel, a pass with few pixels and many samples per pixel (one rank's stripes of an
+// 8-GPU frame: 512 spp) is a latency-bound loop of dependent loads on a nearly empty chip.
+constexpr uint32_t kResolveLanes = 8u;
 __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, uint32_t nlights, const float* __restrict__ slot_L,
                                                      const uint32_t* __restrict__ sample_slot,
                                                      float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= ps.npix) return;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = gid % kResolveLanes;
+    const bool live = gid / kResolveLanes < ps.npix;
+    const uint32_t p = live ? gid / kResolveLanes : ps.npix - 1u;        // surplus groups of the last block shadow the last pixel
     const uint32_t spp = ps.nsamples / ps.npix;
     const uint32_t pixel = ps.use_explicit ? ps.explicit_pixel : pass_pixel(ps, width, p);
     f3 sum = mk3(0, 0, 0), sumsq = mk3(0, 0, 0);
@@ -542,8 +550,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
         sumsq = mk3(film_sumsq[3ull * pixel], film_sumsq[3ull * pixel + 1], film_sumsq[3ull * pixel + 2]);
         n = film_n[pixel];
     }
-    for (uint32_t s = 0; s < spp; ++s) {
-        const uint32_t sl = sample_slot[s * ps.npix + p];
+    const int group_lane0 = lane_id() & ~(int)(kResolveLanes - 1u);
+    for (uint32_t s0 = 0; s0 < spp; s0 += kResolveLanes) {
+        const uint32_t sl = s0 + j < spp ? sample_slot[(s0 + j) * ps.npix + p] : 0xFFFFFFFFu;
         const float* L = slot_L + 3ull * ((size_t)sl * ps.nodes_per_sample * nlights);
         f3 c = mk3(0.0f, 0.0f, 0.0f);                                   // primary miss: RGB::black(), mod.rs:100
         if (sl != 0xFFFFFFFFu) switch (ps.recursions) {
@@ -552,13 +561,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
             case 2: c = node_radiance<2>(L, ps, nlights, 0, 0); break;
             default: c = node_radiance<3>(L, ps, nlights, 0, 0); break;
         }
-        // PixelData::add_sample, film.rs:20-24
-        sum = add3(sum, c);
-        sumsq = add3(sumsq, mk3(c.x * c.x, c.y * c.y, c.z * c.z));
-        n += 1u;
-        if (ps.use_explicit) { debug_color[0] = c.x; debug_color[1] = c.y; debug_color[2] = c.z; }
+#pragma unroll
+        for (uint32_t k = 0; k < kResolveLanes; ++k) {
+            const f3 ck = mk3(__shfl(c.x, group_lane0 + (int)k, 64), __shfl(c.y, group_lane0 + (int)k, 64), __shfl(c.z, group_lane0 + (int)k, 64));
+            if (s0 + k < spp) {
+                // PixelData::add_sample, film.rs:20-24
+                sum = add3(sum, ck);
+                sumsq = add3(sumsq, mk3(ck.x * ck.x, ck.y * ck.y, ck.z * ck.z));
+                n += 1u;
+                if (ps.use_explicit && j == 0u) { debug_color[0] = ck.x; debug_color[1] = ck.y; debug_color[2] = ck.z; }
+            }
+        }
     }
-    if (!ps.use_explicit) {
+    if (!ps.use_explicit && live && j == 0u) {
         film_sum[3ull * pixel] = sum.x; film_sum[3ull * pixel + 1] = sum.y; film_sum[3ull * pixel + 2] = sum.z;
         film_sumsq[3ull * pixel] = sumsq.x; film_sumsq[3ull * pixel + 1] = sumsq.y; film_sumsq[3ull * pixel + 2] = sumsq.z;
         film_n[pixel] = n;
@@ -704,7 +719,7 @@ hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DSc
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
 {
-    dim3 block(256), grid((ps.npix + 255) / 256);
+    dim3 block(256), grid((unsigned)(((size_t)ps.npix * kResolveLanes + 255) / 256));
     hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, ps, width, nlights, slot_L, sample_slot, film_sum, film_sumsq, film_n, debug_color);
     return hipGetLastError();
 }
