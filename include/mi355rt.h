@@ -194,7 +194,7 @@ int mi355rt_debug_numerics(mi355rt_handle* h, const float* a, const float* b, si
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
 
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,
- * [4] node bytes, [5] triangle bytes, [6] nodes staged in LDS, [7] reserved */
+ * [4] node bytes, [5] triangle bytes, [6], [7] reserved (0) */
 int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8]);
 /* reference-exact mode only: out[0] octree nodes, [1] inner, [2] leaves, [3] empty leaves, [4] depth,
  * [5] triangle references (the quantities of SURVEY.md 6.2) */

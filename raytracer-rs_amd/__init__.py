@@ -323,7 +323,7 @@ class RayTracer:
         out = np.zeros(8, np.uint32)
         self._check(lib().mi355rt_accel_stats(self._h, _up(out)))
         return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), max_leaf=int(out[3]),
-                    node_bytes=int(out[4]), tri_bytes=int(out[5]), lds_nodes=int(out[6]))
+                    node_bytes=int(out[4]), tri_bytes=int(out[5]))
 
     def octree_stats(self):
         out = np.zeros(8, np.uint32)

@@ -40,7 +40,6 @@ struct DScene {
     int32_t root;
     uint32_t nlights;
     uint32_t ntri;
-    uint32_t lds_nodes;       // nodes [0, lds_nodes) are staged in LDS by the trace kernel
 };
 
 struct DCamera {

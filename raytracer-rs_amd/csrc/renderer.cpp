@@ -159,7 +159,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_texels, texels.data(), texels.size() * sizeof(float))) return bail();
     dscene_.nodes = d_nodes; dscene_.tris = d_tris; dscene_.normals = d_normals; dscene_.materials = d_mats;
     dscene_.lights = d_lights; dscene_.textures = d_tex; dscene_.texels = d_texels; dscene_.table = d_table;
-    dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri; dscene_.lds_nodes = 0;
+    dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri;
     dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr;
     if (cfg.flags & MI355RT_FLAG_OCTREE_SEMANTICS) {
         // the reference's own structure (OctTreeIntersector::with_triangles_per_leaf, OCT:66-81)
