@@ -18,6 +18,9 @@
 //   resolve        : per pixel, combine the per-node light terms in the reference's own summation
 //                    order (mod.rs:154-175) and add the samples to the film in sample order
 //                    (film.rs:20-24).
+// A frame is rendered as several such passes at once: renderer.cpp deals the rows to concurrent slices,
+// each with its own stream and pass buffers, so the kernels of one slice fill the drain window at the end
+// of another slice's (persistent) trace launch.  The pixels of a pass are walked in 8x8 tiles (pass_pixel).
 //
 // Numerics: compiled with -ffp-contract=off; everything that decides a result (Moller-Trumbore,
 // shading, camera, film, tonemap) is IEEE f32 in the reference's operation order.  Only the BVH box
