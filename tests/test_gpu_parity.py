@@ -487,3 +487,36 @@ def test_large_random_scene_deep_tree(pkg, scenes, oracle):
     assert c.primary_hits > 0
     gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
     assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+
+
+def test_headless_cli_renders_the_library_frame(pkg, scenes, tmp_path):
+    """bin/raytracer (the reference's `raytracer` binary without the window): same flags, the
+    `fps: ... primary rays/s: ...` lines, and the PPM it writes holds exactly the pixels the library returns
+    for the same seed — both in the reference's 50-row progressive mode and with --spp."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracer-rs_amd", "bin", "raytracer")
+    scene = os.path.join(GOLDEN, "scenes", "ico2.scene")
+    w, h = 96, 70
+    for extra, frames in ((["-i", "2"], None), (["--spp", "3"], 3)):
+        out = str(tmp_path / "o.ppm")
+        r = subprocess.run([exe, "-f", scene, "--width", str(w), "--height", str(h), "--seed", "4", "--out", out] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "number of triangles: 608" in r.stdout and "max triangles per leaf: 70" in r.stdout
+        assert len(re.findall(r"fps: [0-9.]+ +primary rays/s: ", r.stdout)) >= (2 if frames is None else 1)
+        assert "mean fps" in r.stdout or "mean" in r.stdout
+        rt = make(pkg, scenes, "ico2", w, h, seed=4)
+        if frames is None:
+            rt.trace_frame_additive(); rt.trace_frame_additive()
+        else:
+            rt.render(frames)
+        ldr = rt.get_tonemapped_pixels()
+        data = open(out, "rb").read()
+        header = ("P6\n%d %d\n255\n" % (w, h)).encode()
+        assert data.startswith(header) and len(data) == len(header) + 3 * w * h
+        rgb = np.frombuffer(data[len(header):], np.uint8).reshape(-1, 3).astype(np.uint32)
+        assert np.array_equal((rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2], ldr & 0xFFFFFF)
+    bad = subprocess.run([exe, "-f", str(tmp_path / "missing.dae")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and bad.stderr.startswith("Error: ")
