@@ -520,3 +520,33 @@ def test_headless_cli_renders_the_library_frame(pkg, scenes, tmp_path):
         assert np.array_equal((rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2], ldr & 0xFFFFFF)
     bad = subprocess.run([exe, "-f", str(tmp_path / "missing.dae")], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and bad.stderr.startswith("Error: ")
+
+
+@pytest.mark.parametrize("name,spp", [("ico2", 64), ("4boxes", 256), ("thai2", 64)])
+def test_baseline_configs_at_full_size(pkg, scenes, name, spp):
+    """BASELINE configs 2-4 at their full sizes (1920x1080, 64 / 256 / 64 spp), through properties that do
+    not need the oracle: every pixel holds spp samples, the ray counters obey the radiance tree (2 reflection
+    rays per primary hit, one per hit after that; at most one shadow ray per shading point and light), the
+    frame is bit-identical run to run, for another slice count, and when it is split into two progressive
+    halves; variance estimates are finite and the packed pixels are opaque."""
+    w, h = 1920, 1080
+    rt = make(pkg, scenes, name, w, h, seed=1)
+    c = rt.render(spp)
+    s1, q1, n1 = rt.film.pixel_datas()
+    assert np.all(n1 == spp) and c.primary == w * h * spp
+    lvl1 = 2 * c.primary_hits
+    assert lvl1 <= c.bounce <= lvl1 + lvl1                         # level-2 rays: one per level-1 hit
+    assert c.shadow <= (c.primary_hits + c.bounce) * len(scenes(name)["lights"])
+    assert np.isfinite(s1).all() and np.isfinite(q1).all() and (s1 >= 0).all()
+    var = rt.film.get_estimated_variances()
+    assert np.isfinite(var).all() and (var >= -1e-3).all()
+    ldr = rt.get_tonemapped_pixels()
+    assert np.all(ldr >> 24 == 255)
+    other = make(pkg, scenes, name, w, h, seed=1)
+    other.set_slices(1 if rt.get_slices() != 1 else 2)
+    other.render(spp // 2); other.render(spp - spp // 2)
+    s2, q2, n2 = other.film.pixel_datas()
+    assert np.array_equal(n2, n1) and np.array_equal(bits(s2), bits(s1)) and np.array_equal(bits(q2), bits(q1))
+    rt.film.clear(); c2 = rt.render(spp)
+    assert (c2.bounce, c2.shadow, c2.primary_hits) == (c.bounce, c.shadow, c.primary_hits)
+    assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(s1))
