@@ -115,8 +115,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     tot = dict(primary=0, bounce=0, shadow=0, trace_ms=0.0, launches=0, gpu_ms=0.0)
+    step_ms = []
     for _ in range(args.steps):
-        c = step()
+        ts = time.perf_counter()
+        c = step()                                                 # synchronous: the frame is complete when it returns
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         tot["primary"] += c.primary; tot["bounce"] += c.bounce; tot["shadow"] += c.shadow
     sync()
     elapsed = time.perf_counter() - t0
@@ -161,6 +164,7 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_median_rank0": round(sorted(step_ms)[len(step_ms) // 2], 3), "ms_per_step_min_rank0": round(min(step_ms), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s 1920x1080, %d spp per GPU (frame = %d spp), recursions 2 / spread 1, %s, "
