@@ -80,3 +80,36 @@ def test_null_handle_calls_are_safe(pkg):
     assert lib.mi355rt_render(None, 1, None) == -1
     assert lib.mi355rt_width(None) == 0
     lib.mi355rt_destroy(None)
+
+
+def test_rust_shim_binds_only_declared_entry_points():
+    """The (uncompiled) Rust shim of INTEGRATION.md declares its extern "C" functions by hand: every one of
+    them must be an entry point of include/mi355rt.h, with the same number of parameters, and the #[repr(C)]
+    structs it passes must list the fields of the header's structs in the header's order."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rust = open(os.path.join(root, "raytracer-rs_amd", "integration", "rust_shim", "src", "lib.rs")).read()
+    header = open(os.path.join(root, "include", "mi355rt.h")).read()
+    header_nc = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    decls = {m.group(1): m.group(2) for m in re.finditer(r"\b(mi355rt_\w+)\s*\(([^;{]*?)\)\s*;", header_nc)}
+    externs = re.findall(r"fn\s+(mi355rt_\w+)\s*\(([^)]*)\)", rust)
+    assert len(externs) >= 10
+    for name, params in externs:
+        assert name in decls, "%s is not declared in include/mi355rt.h" % name
+        n_rust = len([p for p in params.split(",") if p.strip()])
+        c_params = decls[name].strip()
+        n_c = 0 if c_params in ("", "void") else len([p for p in c_params.split(",") if p.strip()])
+        assert n_rust == n_c, "%s: %d parameters in the shim, %d in the header" % (name, n_rust, n_c)
+    for struct in ("mi355rt_material", "mi355rt_light", "mi355rt_texture", "mi355rt_scene_desc", "mi355rt_config"):
+        m = re.search(r"typedef struct %s\s*\{(.*?)\}\s*%s\s*;" % (struct, struct), header_nc, re.S)
+        assert m, struct
+        c_fields = []
+        for decl in m.group(1).split(";"):
+            for d in (x for x in decl.split(",") if x.strip()):      # "uint32_t width, height" declares two fields
+                c_fields.append(re.sub(r"\[.*?\]", "", d.strip().split()[-1]).lstrip("*"))
+        r = re.search(r"struct\s+%s\s*\{(.*?)\}" % struct, rust, re.S)
+        if not r:
+            continue            # the shim need not mirror every struct
+        r_fields = [f.split(":")[0].replace("pub", "").strip() for f in re.sub(r"//.*", "", r.group(1)).split(",") if ":" in f]
+        assert r_fields == c_fields, "%s: shim fields %s, header fields %s" % (struct, r_fields, c_fields)
