@@ -622,8 +622,7 @@ bool Renderer::film_clear()
     HIP_TRY(hipMemsetAsync(d_film_sum_, 0, npix * 12, stream_));
     HIP_TRY(hipMemsetAsync(d_film_sumsq_, 0, npix * 12, stream_));
     HIP_TRY(hipMemsetAsync(d_film_n_, 0, npix * 4, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
-    return true;
+    return true;            // stream-ordered: every later call on this handle starts on the same stream
 }
 
 bool Renderer::intersect(const float* rays6, size_t n, float* tuv, uint32_t* prim, uint8_t* blocked)
