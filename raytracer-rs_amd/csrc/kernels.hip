@@ -475,12 +475,25 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene s
                         pcg4d(h0, h1, h2, h3);
                         uint32_t jx = __umulhi(h0, 65535u);                            // uniform in [0, 65534], sample_generator.rs:32
                         const float4* __restrict__ table = (const float4*)sc.table;
+                        // The walk of mod.rs:187-189 / sample_generator.rs:27 — take the first entry from jx on
+                        // (wrapping at 65535) that lies in the hemisphere of n — fetched FOUR entries at a time:
+                        // as a loop of single dependent loads it runs as long as the unluckiest lane of the wave
+                        // (~7 cache latencies per child); four consecutive entries are one or two cache lines.
                         float4 tv = table[jx];
-                        uint32_t guard = 0u;
-                        while (tv.x * n.x + tv.y * n.y + tv.z * n.z <= 0.0f && guard < kNumSamples) {   // mod.rs:187-189
-                            jx = (jx + 1u) % kSampleMax;                               // sample_generator.rs:27
-                            tv = table[jx];
-                            ++guard;
+                        for (uint32_t guard = 0u; tv.x * n.x + tv.y * n.y + tv.z * n.z <= 0.0f && guard < kNumSamples; guard += 4u) {
+                            const uint32_t j1 = jx + 1u == kSampleMax ? 0u : jx + 1u;
+                            const uint32_t j2 = j1 + 1u == kSampleMax ? 0u : j1 + 1u;
+                            const uint32_t j3 = j2 + 1u == kSampleMax ? 0u : j2 + 1u;
+                            const uint32_t j4 = j3 + 1u == kSampleMax ? 0u : j3 + 1u;
+                            const float4 t1 = table[j1], t2 = table[j2], t3 = table[j3], t4 = table[j4];
+                            const bool r1 = t1.x * n.x + t1.y * n.y + t1.z * n.z <= 0.0f, r2 = t2.x * n.x + t2.y * n.y + t2.z * n.z <= 0.0f;
+                            const bool r3 = t3.x * n.x + t3.y * n.y + t3.z * n.z <= 0.0f;
+                            // the reference stops at the first accepted entry, or after kNumSamples steps with whatever it holds
+                            const uint32_t left = kNumSamples - guard;           // steps still allowed (>= 1)
+                            if (!r1 || left == 1u) { tv = t1; jx = j1; break; }
+                            if (!r2 || left == 2u) { tv = t2; jx = j2; break; }
+                            if (!r3 || left == 3u) { tv = t3; jx = j3; break; }
+                            tv = t4; jx = j4;
                         }
                         bd = mk3(tv.x, tv.y, tv.z);
                         bo = add3(hp, sscale(0.00001f, bd));                           // mod.rs:192-193
