@@ -1,34 +1,44 @@
 #!/usr/bin/env python3
 """bench.py — the reference's headline workload on MI355X.
 
-A "step" is one frame of the render hot path: thai2 (20 049 triangles) at 1920x1080, 64 samples per
-pixel per GPU, RECURSIONS = 2 / SUB_SPREAD = 1, the reference's own pixel->ray mapping, seed 1,
-followed by the tonemapped read-out into device memory and (N > 1) the RCCL gather of the row
-stripes to every rank.  Scene, BVH and film are resident in HBM before the timed region starts.
+Default mode (`--mode frame`): a "step" is one frame of the render hot path: thai2 (20 049 triangles) at
+1920x1080, 64 samples per pixel per GPU, RECURSIONS = 2 / SUB_SPREAD = 1, the reference's own pixel->ray
+mapping, seed 1, followed by the tonemapped read-out into device memory and (N > 1) the gather of the row
+stripes.  Scene, BVH and film are resident in HBM before the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Weak scaling: every GPU traces 1920*1080*64 primary samples.  With N GPUs the frame is the same
-1920x1080 image at 64*N spp, rows dealt to the ranks in stripes of 8 (mi355rt_config.stripe_*), so
-each rank owns 1/N of the rows at N times the spp.  The counter RNG is keyed by (pixel, sample#), so
-the image is the one a single GPU would produce.  No collective on the data path; one
-all_gather of the packed u32 stripes per frame.
+  --scaling weak (default)  every GPU traces 1920*1080*64 primary samples; with N GPUs the frame is the same image
+                            at 64*N spp, rows dealt to the ranks in stripes of 8.
+  --scaling strong          the frame is FIXED (1920x1080x64 spp, or --config c5: 3840x2160x256 spp, BASELINE config 5)
+                            and its rows are dealt to the N ranks.
+  --mode dropin             the loop the reference binary runs (main.rs:197-207) at its defaults (thai2, 1024x768):
+                            a step is trace_frame_additive() + get_tonemapped_pixels(); metric = primary rays/s,
+                            the reference's own stats.rs:27 definition.  N = 1 only.
 
 Rank 0 prints ONE JSON line (see the repo instructions for the contract).  Extra objects:
-  roofline      dominant kernel = trace_kernel (closest-hit traversal).  achieved = algorithmic bytes
-                (node bytes x nodes visited + 48 B x triangles tested + 96 B per ray; this
-                build's node is 32 B, not the 64 B the survey assumed; step counts measured live by the
-                instrumented kernel variant) / summed HIP-event time of
-                the trace launches of the timed frames.  peak = 8000 GB/s (HBM3E spec).  The scene is
-                cache-resident, so this is a LOGICAL rate, not HBM traffic.
-  cpu_baseline  the CPU oracle (C restatement of the reference: octree, recursive radiance) timed on this
-                box's host cores on a bounded sample of the same frame.
+  roofline      dominant kernel = trace_kernel (closest-hit traversal).  It is bound by vector-ALU ISSUE, not by
+                memory (the 1.5 MB scene is cache-resident): `bound` = "valu", achieved = VALU wave-instructions per
+                second of the secondary trace launches (SQ_INSTS_VALU of a rocprofv3 --pmc child pass of THIS run /
+                HIP-event launch time), peak = 1024 SIMDs x clock / 4 cycles per wave64 instruction.  Next to it:
+                the useful-lane fractions of the inner-node and triangle sections (live, MI355RT_FLAG_COUNT_STEPS),
+                the SURVEY.md 8d LOGICAL byte rate (labelled logical: it exceeds the HBM peak because node and
+                triangle bytes are cache hits) and the measured HBM traffic per launch (`traffic`, PMC FETCH_SIZE x 2 +
+                WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  PMC fields are null when the child passes
+                are skipped (--no-pmc, N > 1) or fail.
+  cpu_baseline  the CPU oracle (C restatement of the reference: octree, recursive radiance) timed on this box's
+                host cores on a bounded sample of the same workload.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,30 +48,160 @@ SCENE = "thai2"
 WIDTH, HEIGHT, SPP = 1920, 1080, 64
 STRIPE_ROWS = 8
 HBM_PEAK_GBS = 8000.0
+NUM_SIMDS = 1024            # 256 CUs x 4
+NUM_SE = 32                 # 8 XCDs x 4 shader engines: SQ_BUSY_CYCLES is summed over them
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=["frame", "dropin"], default="frame")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--config", choices=["c4", "c5"], default="c4", help="c4: 1920x1080x64 (headline); c5: 3840x2160x256 (strong scaling only)")
     ap.add_argument("--scene", default=SCENE)
-    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline PMC fields become null)")
+    ap.add_argument("--native-gather", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1: gather the stripes with the library's own RCCL path (on), torch.distributed (off), or try native first")
     ap.add_argument("--fix-row-index", action="store_true",
                     help="v = idx / width instead of the reference's idx / height (SURVEY.md 8d: reported next to the headline, never as it)")
     ap.add_argument("--slices", type=int, default=0, help="concurrent frame slices of the timed frames (0: library default)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 5 if args.mode == "frame" else 2000
+    if args.warmup is None:
+        args.warmup = 2 if args.mode == "frame" else 100
+    return args
 
-    import numpy as np
-    import torch
+
+# ------------------------------------------------------------------------------------------------------------------
+# rocprofv3 --pmc child passes (N = 1, rank 0, BEFORE this process touches the GPU): the same frame under counter
+# collection, one pass per counter group (TCC slots: FETCH_SIZE and WRITE_SIZE cannot share a pass).
+PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"],
+              ["FETCH_SIZE"], ["WRITE_SIZE"]]
+
+
+def pmc_child(args):
+    """What runs under rocprofv3: two frames of the benchmark workload with ONE slice (so that kernels do not overlap)."""
     import __graft_entry__ as ge
+    import importlib
+    pkg = ge.load_package()
+    scene_io = importlib.import_module("raytracer_rs_amd.scene_io")
+    scene = scene_io.load_scene_file(os.path.join(ge.SCENES, args.scene + ".scene"))
+    if args.mode == "dropin":
+        rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, 1024, 768, seed=1)
+        for _ in range(40):
+            rt.trace_frame_additive()
+        rt.get_tonemapped_pixels()
+        return
+    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, WIDTH, HEIGHT, seed=1,
+                                          flags=pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0)
+    rt.set_slices(1)
+    for _ in range(2):
+        rt.film.clear()
+        rt.render(args.spp or SPP)
+
+
+def run_pmc_passes(args, kernel_substr):
+    """-> dict counter -> (sum over dispatches, dispatches) for kernels whose name contains kernel_substr; {} on failure."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    out = {}
+    base = tempfile.mkdtemp(prefix="mi355rt_pmc_", dir="/tmp")
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
+             "--mode", args.mode, "--scene", args.scene] + (["--fix-row-index"] if args.fix_row_index else []) + (["--spp", str(args.spp)] if args.spp else [])
+    note = None
+    try:
+        for gi, group in enumerate(PMC_GROUPS):
+            d = os.path.join(base, "g%d" % gi)
+            cmd = [exe, "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                note = "rocprofv3 pass %d timed out" % gi
+                break
+            if r.returncode != 0:
+                note = "rocprofv3 pass %d failed (rc %d): %s" % (gi, r.returncode, (r.stderr or "")[-200:].replace("\n", " "))
+                break
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                seen = {}
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr not in row["Kernel_Name"]:
+                        continue
+                    name = row["Counter_Name"]
+                    acc = out.setdefault(name, [0.0, set()])
+                    acc[0] += float(row["Counter_Value"]); acc[1].add(row["Dispatch_Id"])
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return {k: (v[0], len(v[1])) for k, v in out.items()}, note
+
+
+def cpu_model():
+    model, phys = "unknown", None
+    try:
+        cores = set(); pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                pid = cid = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, phys, usable
+
+
+def oracle_build_flags(ge):
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.startswith("CFLAGS"):
+                return line.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+    if args.mode == "dropin" and world != 1:
+        raise SystemExit("--mode dropin is a single-GPU loop")
+    if args.config == "c5" and args.scaling != "strong":
+        raise SystemExit("--config c5 is the fixed 3840x2160x256 frame: use --scaling strong")
+
+    # counter passes first: this process has not initialised the GPU yet, so the children have the device to themselves
+    pmc, pmc_note = ({}, "skipped (--no-pmc)") if args.no_pmc else ({}, "skipped (N > 1)")
+    if not args.no_pmc and world == 1:
+        pmc, pmc_note = run_pmc_passes(args, "fused_pass_kernel" if args.mode == "dropin" else "trace_kernel<false, false>")
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -75,10 +215,14 @@ def main():
     import importlib
     scene_io = importlib.import_module("raytracer_rs_amd.scene_io")
     scene = scene_io.load_scene_file(os.path.join(ge.SCENES, args.scene + ".scene"))
-    spp = args.spp * world
-    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, WIDTH, HEIGHT, seed=1, device=local_rank,
-                                          stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_world=world,
-                                          flags=0)
+    if args.mode == "dropin":
+        return dropin_mode(args, ge, pkg, scene, pmc, pmc_note)
+
+    width, height = (3840, 2160) if args.config == "c5" else (WIDTH, HEIGHT)
+    base_spp = args.spp or (256 if args.config == "c5" else SPP)
+    spp = base_spp * world if args.scaling == "weak" else base_spp
+    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, width, height, seed=1, device=local_rank,
+                                          stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_world=world, flags=0)
     base_flags = pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0
     rt.set_flags(base_flags)
     if args.slices:
@@ -86,43 +230,74 @@ def main():
     slices = rt.get_slices()
     stripes = importlib.import_module("raytracer_rs_amd.stripes")
     rows = rt.owned_rows()
-    assert list(rows) == stripes.owned_rows(HEIGHT, STRIPE_ROWS, rank, world)
-    fg = stripes.FrameGather(HEIGHT, WIDTH, STRIPE_ROWS, world, "cuda")
+    assert list(rows) == stripes.owned_rows(height, STRIPE_ROWS, rank, world)
+    fg = stripes.FrameGather(height, width, STRIPE_ROWS, world, "cuda")
     stripe = fg.stripe_buffer("cuda")
+    gather_kind = "none (1 GPU)"
+    native = None
+    if world > 1 and args.native_gather != "off":
+        try:
+            native = stripes.NativeGather(pkg, rt, dist, rank, world)
+            gather_kind = "library RCCL (mi355rt_comm_*: grouped ncclSend/ncclRecv of the u32 stripes to rank 0 + broadcast-free placement)"
+        except Exception as e:                                    # noqa: BLE001 — fall back to torch.distributed, say so in the line
+            if args.native_gather == "on":
+                raise
+            native = None
+            gather_kind = "torch.distributed all_gather_into_tensor (library RCCL path unavailable: %s)" % str(e)[:120]
+    elif world > 1:
+        gather_kind = "torch.distributed all_gather_into_tensor"
+    cur_stream = torch.cuda.current_stream().cuda_stream
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    gather_ms = []
+
+    def step(time_gather=False):
         rt.film.clear()
         counts = rt.render(spp)                                   # synchronous: returns when the frame is traced
-        rt.tonemap_owned_rows_device(stripe.data_ptr(), rows.size * WIDTH)
-        fg.gather(dist, stripe)                                    # every rank ends up with the full frame
+        t0 = time.perf_counter()
+        if native is not None:
+            native.gather()                                        # tonemap + RCCL inside the library, on its own stream
+        else:
+            rt.tonemap_owned_rows_device(stripe.data_ptr(), rows.size * width, stream=cur_stream)   # ordered on torch's stream
+            fg.gather(dist, stripe)
+        if time_gather:
+            torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - t0) * 1e3)
         return counts
 
-    # instrumented frame (untimed): BVH nodes visited / triangles tested per ray for the roofline figure
+    # instrumented frame (untimed): nodes visited / triangles tested per ray, useful-lane fractions of the two sections
     rt.set_flags(base_flags | pkg.FLAG_COUNT_STEPS)
     rt.film.clear()
     c = rt.render(max(1, min(4, spp)))
-    nodes_per_ray = c.nodes_visited / max(1, c.primary + c.bounce + c.shadow)
-    tris_per_ray = c.tris_tested / max(1, c.primary + c.bounce + c.shadow)
+    inst_rays = max(1, c.primary + c.bounce + c.shadow)
+    nodes_per_ray = c.nodes_visited / inst_rays
+    tris_per_ray = c.tris_tested / inst_rays
+    lane_inner = c.nodes_visited / (64.0 * c.inner_execs) if c.inner_execs else None
+    lane_leaf = c.tris_tested / (64.0 * c.leaf_execs) if c.leaf_execs else None
     rt.set_flags(base_flags)
 
     for _ in range(args.warmup):
         step()
     sync()
     t0 = time.perf_counter()
-    tot = dict(primary=0, bounce=0, shadow=0, trace_ms=0.0, launches=0, gpu_ms=0.0)
+    tot = dict(primary=0, bounce=0, shadow=0, culled=0, trace_ms=0.0, launches=0, gpu_ms=0.0)
     step_ms = []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        c = step()                                                 # synchronous: the frame is complete when it returns
+        c = step()                                                 # the frame is complete when render() returns; the gather is queued
         step_ms.append((time.perf_counter() - ts) * 1e3)
-        tot["primary"] += c.primary; tot["bounce"] += c.bounce; tot["shadow"] += c.shadow
+        tot["primary"] += c.primary; tot["bounce"] += c.bounce; tot["shadow"] += c.shadow; tot["culled"] += c.primary_culled
     sync()
     elapsed = time.perf_counter() - t0
+
+    # gather timed on its own (render excluded): a few frames with a device synchronisation after the gather
+    for _ in range(2):
+        step(time_gather=True)
+    sync()
 
     # Kernel-timing loop for the roofline: the same frames again with ONE slice and HIP events around every
     # trace launch (on the stream it is launched on).  The frames above run several slices concurrently:
@@ -141,7 +316,7 @@ def main():
     sync()
     serial_ms_per_step = (time.perf_counter() - t1) / ksteps * 1e3
 
-    stats = torch.tensor([elapsed, tot["primary"], tot["bounce"], tot["shadow"], tot["trace_ms"], tot["launches"], krays],
+    stats = torch.tensor([elapsed, tot["primary"], tot["bounce"], tot["shadow"], tot["culled"], tot["trace_ms"], tot["launches"], krays],
                          dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -149,15 +324,72 @@ def main():
         elapsed = float(tmax[0]); vals = [float(x) for x in sums]
     else:
         vals = [float(x) for x in stats[1:]]
-    primary, bounce, shadow, trace_ms, launches, krays = vals
+    primary, bounce, shadow, culled, trace_ms, launches, krays = vals
     total_rays = primary + bounce + shadow
 
     if rank == 0:
         acc = rt.accel_stats()
-        node_bytes = acc["node_bytes"] / max(acc["nodes"], 1)        # 32 B: both child boxes in half precision (SURVEY assumed 64 B)
+        node_bytes = acc["node_bytes"] / max(acc["nodes"], 1)
         bytes_per_ray = node_bytes * nodes_per_ray + 48.0 * tris_per_ray + 96.0
-        # trace_ms is summed over ranks and total_rays too: the ratio is the per-GPU logical rate
-        achieved = krays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        avg_launch_s = trace_ms * 1e-3 / max(launches, 1)
+        logical_gbs = krays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        prop = torch.cuda.get_device_properties(local_rank)
+        clock_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
+        peak_winst = NUM_SIMDS * clock_hz / 4.0 / 1e9                     # G wave64 VALU instructions per second
+        roof = {"bound": "valu", "kernel": "trace_kernel<secondary>", "unit": "G wave-instr/s", "peak": round(peak_winst, 1),
+                "peak_is": "%d SIMDs x %.0f MHz / 4 cycles per wave64 VALU instruction" % (NUM_SIMDS, clock_hz / 1e6),
+                "achieved": None, "frac": None,
+                "useful_lane_frac_inner": round(lane_inner, 3) if lane_inner else None, "useful_lane_frac_leaf": round(lane_leaf, 3) if lane_leaf else None,
+                "launches": int(launches), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2), "node_bytes": node_bytes,
+                "logical": {"what": "SURVEY.md 8d algorithmic bytes: node_bytes x nodes + 48 x triangles + 96 per ray; node and triangle bytes are CACHE hits "
+                                    "(1.5 MB scene), so this is not HBM traffic and may exceed the HBM peak",
+                            "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_launch": round(krays * bytes_per_ray / max(launches, 1), 1),
+                            "gbs": round(logical_gbs, 1), "frac_of_hbm_peak": round(logical_gbs / HBM_PEAK_GBS, 4)},
+                "traffic": None, "hbm": None,
+                "timing": "HIP events around every trace launch in a second loop of %d frames with 1 slice (%.2f ms/frame); the headline frames run %d "
+                          "concurrent slices whose kernels overlap" % (ksteps, serial_ms_per_step, slices),
+                "pmc": {"source": "rocprofv3 --pmc child passes of this same run (bench.py --pmc-child: 2 frames, 1 slice), secondary trace launches", "note": pmc_note}}
+        # per secondary trace launch of the child == per secondary trace launch here (same frame, same binary)
+        rays_per_sec_launch = (bounce + shadow) / max(args.steps * world, 1)     # secondary rays per frame per GPU ...
+        if "SQ_INSTS_VALU" in pmc:
+            v, n = pmc["SQ_INSTS_VALU"]
+            frame_launches = n / 2.0                                             # the child renders 2 frames
+            inst_per_frame = v / 2.0
+            sec_rays_frame = rays_per_sec_launch
+            sec_ms_frame = None
+            # secondary launches' share of the HIP-event trace time: the child has no timing, use the avg launch duration of this run's loop
+            roof["pmc"]["dispatches"] = n
+            roof["pmc"]["valu_winst_per_secondary_ray"] = round(inst_per_frame / max(sec_rays_frame, 1), 2)
+            roof["pmc"]["salu_inst_per_secondary_ray"] = round(pmc.get("SQ_INSTS_SALU", (0, 0))[0] / 2.0 / max(sec_rays_frame, 1), 2)
+            if "SQ_BUSY_CYCLES" in pmc and pmc["SQ_BUSY_CYCLES"][0] > 0:
+                busy = pmc["SQ_BUSY_CYCLES"][0] / NUM_SE                          # cycles during which the shader engines had waves
+                issue = v * 4.0 / NUM_SIMDS / busy
+                roof["pmc"]["valu_issue_frac_of_busy_cycles"] = round(issue, 4)
+                roof["frac"] = round(issue, 4)
+                roof["achieved"] = round(issue * peak_winst, 1)
+                roof["frac_is"] = "SQ_INSTS_VALU x 4 cycles / %d SIMDs over SQ_BUSY_CYCLES / %d shader engines: the share of busy cycles in which a SIMD's vector ALU issues" % (NUM_SIMDS, NUM_SE)
+            if "SQ_THREAD_CYCLES_VALU" in pmc and v > 0:
+                roof["pmc"]["exec_lanes_per_valu_inst"] = round(pmc["SQ_THREAD_CYCLES_VALU"][0] / v, 1)
+            if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
+                roof["pmc"]["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"][0] / pmc["SQ_WAVE_CYCLES"][0], 3)
+            if lane_inner and lane_leaf and roof["frac"]:
+                # useful share of the issued lane-slots, weighting the two sections by their executions x static length is not
+                # available live; the plain product with the inner-section fraction is the upper estimate
+                roof["useful_issue_frac_upper"] = round(roof["frac"] * max(lane_inner, lane_leaf), 4)
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            f, nf = pmc["FETCH_SIZE"]; w, nw = pmc["WRITE_SIZE"]
+            per_launch = (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0                     # KB -> B; FETCH_SIZE doubled (gfx950 wide reads)
+            roof["traffic"] = round(per_launch, 1)
+            roof["hbm"] = {"bytes_per_launch": round(per_launch, 1), "gbs": round(per_launch / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else None,
+                           "frac_of_hbm_peak": round(per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if avg_launch_s > 0 else None,
+                           "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / dispatches"}
+        if args.scaling == "strong":
+            workload = "%s %dx%d x %d spp FIXED frame dealt to %d GPU(s) in row stripes of %d (strong scaling%s)" % (
+                args.scene, width, height, spp, world, STRIPE_ROWS, ", BASELINE config 5" if args.config == "c5" else "")
+        else:
+            workload = "%s %dx%d, %d spp per GPU (frame = %d spp), rows dealt in stripes of %d" % (args.scene, width, height, base_spp, spp, STRIPE_ROWS)
+        workload += ", recursions 2 / spread 1, " + ("row index FIXED (v = idx / width)" if args.fix_row_index else "reference pixel mapping")
         out = {
             "metric": "Mrays/s (whole node) + ms/frame, 1920x1080x64spp thai2.dae",
             "value": round(total_rays / elapsed / 1e6, 2),
@@ -165,88 +397,134 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "ms_per_step_median_rank0": round(sorted(step_ms)[len(step_ms) // 2], 3), "ms_per_step_min_rank0": round(min(step_ms), 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s 1920x1080, %d spp per GPU (frame = %d spp), recursions 2 / spread 1, %s, "
-                                   "rows dealt in stripes of %d" % (args.scene, args.spp, spp, "row index FIXED (v = idx / width)" if args.fix_row_index else "reference pixel mapping", STRIPE_ROWS),
-                       "scene": args.scene, "width": WIDTH, "height": HEIGHT, "spp_per_gpu": args.spp, "seed": 1,
-                       "slices": slices, "parallelism": "row stripes x%d, RCCL all_gather of u32 stripes" % world},
+            "config": {"workload": workload, "scene": args.scene, "width": width, "height": height, "spp_per_gpu": spp if args.scaling == "strong" else base_spp,
+                       "frame_spp": spp, "seed": 1, "slices": slices, "parallelism": "row stripes x%d" % world, "gather": gather_kind},
             "primary_mrays_per_s": round(primary / elapsed / 1e6, 2),
-            "rays_per_frame": {"primary": primary / args.steps, "bounce": bounce / args.steps, "shadow": shadow / args.steps},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(),
-                         "traffic_source": "offline rocprofv3 --pmc passes of this command (profiles/r01_pmc_traffic_summary.txt): "
-                                           "(2 x FETCH_SIZE + WRITE_SIZE) per secondary trace launch",
-                         "algorithmic_bytes_per_launch": round(krays * bytes_per_ray / max(launches, 1), 1),
-                         "timing": "HIP events around every trace launch in a second loop of %d frames with 1 slice (%.2f ms/frame); the headline "
-                                   "frames run %d concurrent slices whose kernels overlap" % (ksteps, serial_ms_per_step, slices),
-                         "whole_frame_logical_gbs": round(total_rays * bytes_per_ray / elapsed / 1e9, 1),
-                         "kernel": "trace_kernel", "launches": int(launches), "avg_launch_ms": round(trace_ms / max(launches, 1), 4),
-                         "bytes_per_ray": round(bytes_per_ray, 1), "node_bytes": node_bytes, "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
-                         "valu_issue_frac": valu_issue_fraction(),
-                         "note": "logical bytes (SURVEY.md 8d); the 1.5 MB scene is cache-resident, measured HBM traffic is queues + film only; "
-                                 "the kernel is bound by VALU issue (valu_issue_frac, offline SQ counters in profiles/r01_pmc_sq_summary_final.txt)"},
+            "traced_mrays_per_s": round((total_rays - culled) / elapsed / 1e6, 2),
+            "traced_note": "value counts every primary sample (the reference's stats.rs:27 definition); traced_mrays_per_s leaves out the primary "
+                           "samples of chunks the frustum culling skipped without tracing (%.1f %% of the primary samples)" % (100.0 * culled / max(primary, 1)),
+            "rays_per_frame": {"primary": primary / args.steps, "bounce": bounce / args.steps, "shadow": shadow / args.steps, "primary_culled": culled / args.steps},
+            "gather_ms_rank0": round(sorted(gather_ms)[len(gather_ms) // 2], 3) if gather_ms else None,
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ge, scene, args.fix_row_index)
+            out["cpu_baseline"] = cpu_baseline(ge, scene, width, height, args.fix_row_index)
         print(json.dumps(out), flush=True)
+    if native is not None:
+        native.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per secondary trace launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
-    WRITE_SIZE runs of this same command, profiles/r01_pmc_traffic_summary.txt): (2 x FETCH_SIZE + WRITE_SIZE)
-    x 1024 / dispatches — FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.txt")
-    try:
-        text = open(path).read()
-    except OSError:
-        return None
-    vals = {}
-    section = None
-    lines = text.splitlines()
-    for i, line in enumerate(lines):
-        if line.startswith("== "):
-            section = line[3:].strip()
-        if line.startswith("S:trace_kernel<false, fals") and section in ("pmc_fetch", "pmc_write") and i + 1 < len(lines):
-            n = int(line.split("dispatches")[1])
-            name, v = lines[i + 1].split()
-            vals[name] = float(v) * 1024.0 / n
-    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-        return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
-    return None
+# ------------------------------------------------------------------------------------------------------------------
+def dropin_mode(args, ge, pkg, scene, pmc, pmc_note):
+    """The reference binary's loop (main.rs:197-207) at its defaults: thai2, 1024x768; one step = trace_frame_additive()
+    (50 rows x 1 sample = 51 200 primary rays) + get_tonemapped_pixels() (a fresh copy of the whole frame in host memory)."""
+    import numpy as np
+    import torch
+    w, h = 1024, 768
+    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, seed=1)
+    buf = np.empty(w * h, np.uint32)
+
+    def step():
+        n = rt.trace_frame_additive()
+        rt.get_tonemapped_pixels(buf)
+        return n
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    primary = 0
+    for _ in range(args.steps):
+        primary += step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # the two halves on their own
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        rt.trace_frame_additive()
+    rt.last_counts()                                                   # waits for the device
+    trace_only = (time.perf_counter() - t1) / args.steps
+    t2 = time.perf_counter()
+    for _ in range(min(args.steps, 200)):
+        rt.get_tonemapped_pixels(buf)                                  # nothing dirty: the host copy alone
+    copy_only = (time.perf_counter() - t2) / min(args.steps, 200)
+    # kernel time (HIP events around the fused launch) and rays per call
+    rt.set_flags(pkg.FLAG_TIME_KERNELS)
+    kms, rays, kcalls = 0.0, 0, 200
+    for _ in range(kcalls):
+        rt.trace_frame_additive()
+        c = rt.last_counts()
+        kms += c.trace_ms; rays += c.primary + c.bounce + c.shadow
+    rt.set_flags(0)
+    # the multi-launch wavefront rounds on the same calls, for the A/B
+    os.environ["MI355RT_NO_FUSED"] = "1"
+    for _ in range(20):
+        step()
+    t3 = time.perf_counter()
+    for _ in range(200):
+        step()
+    wavefront_ms = (time.perf_counter() - t3) / 200 * 1e3
+    del os.environ["MI355RT_NO_FUSED"]
+    # instrumented call: steps per ray for the logical byte figure
+    rt.set_flags(pkg.FLAG_COUNT_STEPS)
+    rt.trace_frame_additive(); c = rt.last_counts()
+    rt.set_flags(0)
+    r1 = max(1, c.primary + c.bounce + c.shadow)
+    acc = rt.accel_stats()
+    node_bytes = acc["node_bytes"] / max(acc["nodes"], 1)
+    bytes_per_ray = node_bytes * c.nodes_visited / r1 + 48.0 * c.tris_tested / r1 + 96.0
+    avg_kernel_s = kms * 1e-3 / kcalls
+    logical = rays / kcalls * bytes_per_ray / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    roof = {"bound": "latency", "kernel": "fused_pass_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(logical, 1), "frac": round(logical / HBM_PEAK_GBS, 4),
+            "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "rays_per_call": rays / kcalls, "bytes_per_ray": round(bytes_per_ray, 1),
+            "note": "one launch of 800 waves (51 200 samples in 64-sample chunks, each wave takes its chunk through all 4 trace and 3 shade phases): "
+                    "the launch is a chain of dependent cache-latency-bound phases on a chip that is 1/10 full; achieved is the LOGICAL SURVEY 8d byte rate",
+            "traffic": None, "pmc": {"note": pmc_note}}
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        f, nf = pmc["FETCH_SIZE"]; wv, nw = pmc["WRITE_SIZE"]
+        roof["traffic"] = round((2.0 * f / max(nf, 1) + wv / max(nw, 1)) * 1024.0, 1)
+    if "SQ_INSTS_VALU" in pmc:
+        roof["pmc"]["valu_winst_per_launch"] = round(pmc["SQ_INSTS_VALU"][0] / max(pmc["SQ_INSTS_VALU"][1], 1), 1)
+    out = {
+        "metric": "primary rays/s of the reference binary's loop: trace_frame_additive() + get_tonemapped_pixels(), thai2 1024x768 (main.rs:13-15,197-207)",
+        "value": round(primary / elapsed, 1), "unit": "primary rays/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s 1024x768, 50 rows x 1 sample per call (51 200 primary rays), whole-frame u32 read-out into host memory per call" % args.scene,
+                   "scene": args.scene, "width": w, "height": h, "seed": 1},
+        "fps": round(args.steps / elapsed, 1),
+        "ms_trace_frame_additive_only": round(trace_only * 1e3, 4), "ms_get_tonemapped_pixels_clean": round(copy_only * 1e3, 4),
+        "ms_per_step_wavefront_rounds": round(wavefront_ms, 4),
+        "total_mrays_per_s": round(rays / kcalls / (elapsed / args.steps) / 1e6, 2),
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        O = ge.load_oracle()
+        orc = O.Oracle(scene, w, h, seed=1)                              # the reference's default intersector (octree, 70 per leaf)
+        t = time.perf_counter(); calls = 0; prim = 0
+        while time.perf_counter() - t < 12.0 and calls < 400:
+            prim += orc.trace_frame_additive(); orc.get_tonemapped_pixels(); calls += 1
+        dt = time.perf_counter() - t
+        model, phys, usable = cpu_model()
+        out["cpu_baseline"] = {"value": round(prim / dt, 1), "unit": "primary rays/s", "cores": 1, "kind": "port",
+                               "sample": "%d calls of oracle_trace_frame_additive + oracle_get_tonemapped on 1 thread (%.1f s): the reference's loop is serial "
+                                         "(mod.rs:80-117); octree oracle at 70 triangles per leaf" % (calls, dt),
+                               "ms_per_step": round(dt / calls * 1e3, 2), "cpu_model": model, "physical_cores": phys, "build_flags": oracle_build_flags(ge)}
+    print(json.dumps(out), flush=True)
 
 
-def valu_issue_fraction():
-    """Fraction of the time the vector ALUs of the secondary trace launches issue an instruction, from the
-    committed rocprofv3 SQ counter passes (profiles/r01_pmc_sq_summary_final.txt): SQ_INSTS_VALU / 1024 SIMDs
-    x 4 cycles per wave64 instruction over SQ_BUSY_CYCLES / 32 shader engines.  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_sq_summary_final.txt")
-    try:
-        lines = open(path).read().splitlines()
-    except OSError:
-        return None
-    vals = {}
-    take = False
-    for line in lines:
-        if not line.startswith(" "):
-            take = line.startswith("S:trace_kernel<false, fals")
-        elif take:
-            name, v = line.split()
-            vals.setdefault(name, float(v))
-    if "SQ_INSTS_VALU" in vals and vals.get("SQ_BUSY_CYCLES"):
-        return round(vals["SQ_INSTS_VALU"] / 1024.0 * 4.0 / (vals["SQ_BUSY_CYCLES"] / 32.0), 3)
-    return None
-
-
-def cpu_baseline(ge, scene, fix_row_index=False):
+def cpu_baseline(ge, scene, width, height, fix_row_index=False):
     """The oracle (oracle/oracle.c) on this box's host cores, bounded sample of the same workload."""
     O = ge.load_oracle()
-    ncores = min(os.cpu_count() or 1, 64)
-    orc = O.Oracle(scene, WIDTH, HEIGHT, seed=1, flags=O.FLAG_FIX_ROW_INDEX if fix_row_index else 0)
-    # whole 1920x1080 frames at 1 spp, repeated until ~12 s of wall time have been spent
+    model, phys, usable = cpu_model()
+    ncores = usable                                                      # every core this process may run on
+    orc = O.Oracle(scene, width, height, seed=1, flags=O.FLAG_FIX_ROW_INDEX if fix_row_index else 0)
+    # whole frames at 1 spp, repeated until ~12 s of wall time have been spent
     t0 = time.perf_counter()
     tot = dict(primary=0, bounce=0, shadow=0)
     frames = 0
@@ -260,13 +538,15 @@ def cpu_baseline(ge, scene, fix_row_index=False):
     dt = time.perf_counter() - t0
     rays = tot["primary"] + tot["bounce"] + tot["shadow"]
     # single-thread rate on a smaller sample (the reference's real threading model, mod.rs:80-117)
+    r0 = height // 2 - 32
     t1 = time.perf_counter()
-    c1 = orc.render(1, nthreads=1, rows=(508, 572))
+    c1 = orc.render(1, nthreads=1, rows=(r0, r0 + 64))
     dt1 = time.perf_counter() - t1
     rays1 = c1["primary"] + c1["bounce"] + c1["shadow"]
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": ncores, "kind": "port",
-            "sample": "%d spp of the same 1920x1080 thai2 frame (%d primary samples, %.1f s), octree oracle at 70 tris/leaf, %d threads; "
-                      "single_thread_value = 64 rows x 1 spp on 1 thread" % (frames, tot["primary"], dt, ncores),
+            "sample": "%d spp of the same %dx%d frame (%d primary samples, %.1f s), octree oracle at 70 tris/leaf, %d threads (all cores this process may use); "
+                      "single_thread_value = 64 rows x 1 spp on 1 thread" % (frames, width, height, tot["primary"], dt, ncores),
+            "cpu_model": model, "physical_cores": phys, "logical_cpus_usable": usable, "build_flags": oracle_build_flags(ge),
             "primary_mrays_per_s": round(tot["primary"] / dt / 1e6, 4),
             "single_thread_value": round(rays1 / dt1 / 1e6, 4)}
 

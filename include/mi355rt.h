@@ -89,7 +89,7 @@ typedef struct mi355rt_config {
     uint32_t recursions;             /* RECURSIONS = 2, mod.rs:81 (0 selects the default) */
     uint32_t spread;                 /* SUB_SPREAD = 1, mod.rs:82 (0 selects the default) */
     uint32_t flags;                  /* MI355RT_FLAG_* */
-    uint64_t seed;                   /* counter-RNG seed (the reference draws OS entropy) */
+    uint64_t seed;                   /* counter-RNG seed (the reference draws OS entropy); low 32 bits used */
     int32_t device;                  /* HIP device ordinal */
     /* Row-stripe ownership for multi-GPU rendering: this handle renders the stripes of
      * `stripe_rows` rows whose index is congruent to stripe_rank modulo stripe_world.
@@ -104,9 +104,13 @@ typedef struct mi355rt_ray_counts {
     uint64_t bounce;         /* reflection rays, mod.rs:156-158 */
     uint64_t shadow;         /* shadow rays, mod.rs:226 */
     uint64_t primary_hits;
+    uint64_t primary_culled; /* primary samples never traced: their 256-sample chunk lies outside the screen bounds of the
+                              * top BVH boxes (all of them miss, mod.rs:99-100); traced primary rays = primary - primary_culled */
     uint64_t nodes_visited;  /* only with MI355RT_FLAG_COUNT_STEPS */
     uint64_t tris_tested;    /* only with MI355RT_FLAG_COUNT_STEPS */
-    uint64_t trace_launches; /* trace-kernel launches */
+    uint64_t trace_launches; /* trace-kernel launches (a 50-row frame: fused launches) */
+    uint64_t inner_execs;    /* only with MI355RT_FLAG_COUNT_STEPS: wave-level executions of the inner-node section */
+    uint64_t leaf_execs;     /* only with MI355RT_FLAG_COUNT_STEPS: wave-level executions of the triangle section */
     double trace_ms;         /* summed HIP-event time of the trace kernels (MI355RT_FLAG_TIME_KERNELS) */
     double total_ms;         /* HIP-event time of the whole call on the handle's stream */
 } mi355rt_ray_counts;
@@ -134,8 +138,8 @@ uint32_t mi355rt_trace_frame_additive(mi355rt_handle* h);
 /* Whole frame (owned stripes) x spp samples per pixel — the benchmark entry; no reference
  * counterpart (the reference has no spp concept).  counts may be NULL. */
 int mi355rt_render(mi355rt_handle* h, uint32_t spp, mi355rt_ray_counts* counts);
-/* counters of the last trace_frame_additive / render call */
-int mi355rt_last_counts(const mi355rt_handle* h, mi355rt_ray_counts* counts);
+/* counters of the last trace_frame_additive / render call (waits for an asynchronous 50-row frame to finish) */
+int mi355rt_last_counts(mi355rt_handle* h, mi355rt_ray_counts* counts);
 
 /* RayTracer::get_tonemapped_pixels, mod.rs:120-128: width*height u32 0xAARRGGBB (A = 255). */
 int mi355rt_get_tonemapped_pixels(mi355rt_handle* h, uint32_t* out, size_t n);
@@ -143,6 +147,11 @@ int mi355rt_get_tonemapped_pixels(mi355rt_handle* h, uint32_t* out, size_t n);
  * collective library).  Rows owned by this handle only, packed in ascending row order:
  * mi355rt_owned_rows(h) * width values.  Synchronous with respect to the host. */
 int mi355rt_tonemap_owned_rows_device(mi355rt_handle* h, uint32_t* device_out, size_t n);
+/* Same, ASYNCHRONOUS: the kernel is launched on the caller's HIP stream (`hip_stream` is a hipStream_t),
+ * after everything this handle has queued; the call returns at once and the write is ordered with the
+ * caller's other work on that stream (buffer initialisation before, the collective after).  Later calls on
+ * this handle wait for it. */
+int mi355rt_tonemap_owned_rows_device_on_stream(mi355rt_handle* h, uint32_t* device_out, size_t n, void* hip_stream);
 uint32_t mi355rt_owned_rows(const mi355rt_handle* h);
 /* ascending list of the rows this handle owns */
 int mi355rt_owned_row_list(const mi355rt_handle* h, uint32_t* rows, size_t n);
@@ -163,7 +172,11 @@ int mi355rt_camera_get(const mi355rt_handle* h, float rot16[16], float orient16[
 /* Camera::get_ray, camera.rs:80-90, with explicit jitter (xi1, xi2 in [0,1)): out = pos3, dir3 */
 int mi355rt_camera_get_ray(const mi355rt_handle* h, uint32_t u, uint32_t v, float xi1, float xi2, float ray6[6]);
 
+/* Re-seed: afterwards the handle renders what a handle created with this seed renders (the per-sample hash key AND
+ * the 65 536-entry direction table are functions of the seed; only its low 32 bits are used).  The film is kept. */
 int mi355rt_set_seed(mi355rt_handle* h, uint64_t seed);
+/* Run-time flags (FIX_ROW_INDEX, COUNT_STEPS, TIME_KERNELS).  MI355RT_FLAG_OCTREE_SEMANTICS is fixed at creation:
+ * pass the bit as it was created, a call that would change it fails with MI355RT_E_INVALID and changes nothing. */
 int mi355rt_set_flags(mi355rt_handle* h, uint32_t flags);
 /* Number of concurrent frame slices mi355rt_render splits its rows into (1..8, default 3, or the
  * environment variable MI355RT_SLICES).  Each slice runs its wavefront passes on its own HIP stream, so the
@@ -191,6 +204,11 @@ int mi355rt_debug_sample(mi355rt_handle* h, uint32_t pixel, uint32_t sampleno, f
 /* Device arithmetic self-check: quot = a/b, root = sqrt(a), pow32 = a^32 computed exactly as the
  * kernels compute them (IEEE division and square root; powf(x, 32.0) of mod.rs:255). */
 int mi355rt_debug_numerics(mi355rt_handle* h, const float* a, const float* b, size_t n, float* quot, float* root, float* pow32);
+/* intersect_cube_inverse_ray, oct_tree_intersector.rs:348-372, exactly as the reference-exact intersector runs it
+ * on the device: inv_rays6 = n x (origin3, 1/dir3), cubes6 = n x (min3, max3); hit[i] = 1 iff the slab test
+ * passes, tmin[i] = the entry distance it returns (negative when the origin is inside).  Exists so that the
+ * reference's own known-answer vectors (oct_tree_intersector.rs:475-512) run through the HIP path. */
+int mi355rt_debug_slab(mi355rt_handle* h, const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
 
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,

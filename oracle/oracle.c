@@ -705,7 +705,8 @@ void oracle_destroy(oracle_t* o)
     free(o->texs); free(o->texdata); free(o->table); free(o->sum); free(o->sumsq); free(o->nsamp);
     free(o);
 }
-void oracle_set_seed(oracle_t* o, uint64_t seed) { o->seed = seed; }
+/* a re-seeded oracle equals one created with that seed: the direction table is a function of the seed too */
+void oracle_set_seed(oracle_t* o, uint64_t seed) { o->seed = seed; free(o->table); build_table(o); }
 void oracle_set_flags(oracle_t* o, uint32_t flags) { o->flags = flags; }
 
 /* mod.rs:80-117 : 50 rows x width pixels x 1 sample; sample# of a pixel = samples it already holds */

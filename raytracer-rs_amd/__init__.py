@@ -70,13 +70,16 @@ class Config(C.Structure):
 class RayCounts(C.Structure):
     _fields_ = [
         ("primary", C.c_uint64), ("bounce", C.c_uint64), ("shadow", C.c_uint64), ("primary_hits", C.c_uint64),
+        ("primary_culled", C.c_uint64),
         ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("trace_launches", C.c_uint64),
+        ("inner_execs", C.c_uint64), ("leaf_execs", C.c_uint64),
         ("trace_ms", C.c_double), ("total_ms", C.c_double),
     ]
 
     def as_dict(self):
         d = {name: getattr(self, name) for name, _ in self._fields_}
         d["total_rays"] = self.primary + self.bounce + self.shadow
+        d["traced_rays"] = d["total_rays"] - self.primary_culled
         return d
 
 
@@ -97,6 +100,7 @@ ABI = [
     ("mi355rt_last_counts", C.c_int, [_H, C.POINTER(RayCounts)]),
     ("mi355rt_get_tonemapped_pixels", C.c_int, [_H, _U, C.c_size_t]),
     ("mi355rt_tonemap_owned_rows_device", C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    ("mi355rt_tonemap_owned_rows_device_on_stream", C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mi355rt_owned_rows", C.c_uint32, [_H]),
     ("mi355rt_owned_row_list", C.c_int, [_H, _U, C.c_size_t]),
     ("mi355rt_film_get", C.c_int, [_H, _F, _F, _U]),
@@ -117,6 +121,7 @@ ABI = [
     ("mi355rt_get_sample_table", C.c_int, [_H, _F]),
     ("mi355rt_debug_sample", C.c_int, [_H, C.c_uint32, C.c_uint32, _F, _F, C.c_size_t]),
     ("mi355rt_debug_numerics", C.c_int, [_H, _F, _F, C.c_size_t, _F, _F, _F]),
+    ("mi355rt_debug_slab", C.c_int, [_H, _F, _F, C.c_size_t, C.POINTER(C.c_uint8), _F]),
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
     ("mi355rt_octree_stats", C.c_int, [_H, _U]),
@@ -249,8 +254,10 @@ class RayTracer:
             self._check(-4)
         return n
 
-    def get_tonemapped_pixels(self):
-        out = np.zeros(self.width * self.height, np.uint32)
+    def get_tonemapped_pixels(self, out=None):
+        """width*height u32 0xAARRGGBB; `out` (uint32[width*height]) is reused when given"""
+        if out is None:
+            out = np.empty(self.width * self.height, np.uint32)
         self._check(lib().mi355rt_get_tonemapped_pixels(self._h, _up(out), out.size))
         return out
 
@@ -285,8 +292,13 @@ class RayTracer:
             self._check(lib().mi355rt_owned_row_list(self._h, _up(rows), n))
         return rows
 
-    def tonemap_owned_rows_device(self, device_ptr, n):
-        self._check(lib().mi355rt_tonemap_owned_rows_device(self._h, C.c_void_p(device_ptr), n))
+    def tonemap_owned_rows_device(self, device_ptr, n, stream=None):
+        """Packed owned rows into device memory.  stream (a hipStream_t as int, e.g.
+        torch.cuda.current_stream().cuda_stream): asynchronous, ordered on that stream; None: synchronous."""
+        if stream:
+            self._check(lib().mi355rt_tonemap_owned_rows_device_on_stream(self._h, C.c_void_p(device_ptr), n, C.c_void_p(stream)))
+        else:
+            self._check(lib().mi355rt_tonemap_owned_rows_device(self._h, C.c_void_p(device_ptr), n))
 
     def intersect_rays(self, rays6):
         rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
@@ -318,6 +330,14 @@ class RayTracer:
         q = np.zeros_like(a); r = np.zeros_like(a); p = np.zeros_like(a)
         self._check(lib().mi355rt_debug_numerics(self._h, _fp(a), _fp(b), a.size, _fp(q), _fp(r), _fp(p)))
         return q, r, p
+
+    def debug_slab(self, inv_rays6, cubes6):
+        """intersect_cube_inverse_ray on the device: (hit[n] bool, tmin[n])"""
+        r = np.ascontiguousarray(inv_rays6, np.float32).reshape(-1, 6); c = np.ascontiguousarray(cubes6, np.float32).reshape(-1, 6)
+        assert r.shape == c.shape
+        hit = np.zeros(r.shape[0], np.uint8); tmin = np.zeros(r.shape[0], np.float32)
+        self._check(lib().mi355rt_debug_slab(self._h, _fp(r), _fp(c), r.shape[0], hit.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(tmin)))
+        return hit.astype(bool), tmin
 
     def accel_stats(self):
         out = np.zeros(8, np.uint32)

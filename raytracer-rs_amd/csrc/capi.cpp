@@ -113,11 +113,10 @@ int mi355rt_render(mi355rt_handle* h, uint32_t spp, mi355rt_ray_counts* counts)
     return ok ? MI355RT_OK : MI355RT_E_HIP;
 }
 
-int mi355rt_last_counts(const mi355rt_handle* h, mi355rt_ray_counts* counts)
+int mi355rt_last_counts(mi355rt_handle* h, mi355rt_ray_counts* counts)
 {
     if (!h || !counts) return MI355RT_E_INVALID;
-    *counts = h->r->counts;
-    return MI355RT_OK;
+    return h->r->last_counts(*counts) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_get_tonemapped_pixels(mi355rt_handle* h, uint32_t* out, size_t n)
@@ -130,6 +129,13 @@ int mi355rt_tonemap_owned_rows_device(mi355rt_handle* h, uint32_t* device_out, s
 {
     if (!h) return MI355RT_E_INVALID;
     return h->r->tonemap_owned_rows_device(device_out, n) ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+int mi355rt_tonemap_owned_rows_device_on_stream(mi355rt_handle* h, uint32_t* device_out, size_t n, void* hip_stream)
+{
+    if (!h) return MI355RT_E_INVALID;
+    if (!hip_stream) { h->r->last_error = "null stream: use mi355rt_tonemap_owned_rows_device"; return MI355RT_E_INVALID; }
+    return h->r->tonemap_owned_rows_device(device_out, n, (hipStream_t)hip_stream) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 uint32_t mi355rt_owned_rows(const mi355rt_handle* h) { return h ? (uint32_t)h->r->owned_rows.size() : 0u; }
@@ -156,29 +162,13 @@ int mi355rt_film_clear(mi355rt_handle* h)
 int mi355rt_film_get_pixels(mi355rt_handle* h, float* rgb)
 {
     if (!h || !rgb) return MI355RT_E_INVALID;
-    const size_t npix = (size_t)h->r->cfg.width * h->r->cfg.height;
-    std::vector<float> sum(npix * 3); std::vector<uint32_t> n(npix);
-    if (!h->r->film_get(sum.data(), nullptr, n.data())) return MI355RT_E_HIP;
-    for (size_t i = 0; i < npix; ++i) {
-        float inv = 1.0f / (float)n[i];                                          // film.rs:46
-        rgb[3 * i] = sum[3 * i] * inv; rgb[3 * i + 1] = sum[3 * i + 1] * inv; rgb[3 * i + 2] = sum[3 * i + 2] * inv;
-    }
-    return MI355RT_OK;
+    return h->r->film_stat(false, rgb) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_film_get_estimated_variances(mi355rt_handle* h, float* rgb)
 {
     if (!h || !rgb) return MI355RT_E_INVALID;
-    const size_t npix = (size_t)h->r->cfg.width * h->r->cfg.height;
-    std::vector<float> sum(npix * 3), sumsq(npix * 3); std::vector<uint32_t> n(npix);
-    if (!h->r->film_get(sum.data(), sumsq.data(), n.data())) return MI355RT_E_HIP;
-    for (size_t i = 0; i < npix; ++i) {                                          // film.rs:51-67
-        float nn1 = (float)(uint32_t)(n[i] * (n[i] - 1u));
-        float n2n1 = (float)n[i] * nn1;
-        for (int c = 0; c < 3; ++c)
-            rgb[3 * i + c] = (sumsq[3 * i + c] / nn1 - sum[3 * i + c] * sum[3 * i + c] / n2n1) * 50.0f;
-    }
-    return MI355RT_OK;
+    return h->r->film_stat(true, rgb) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_camera_move_rel(mi355rt_handle* h, float x, float y, float z)
@@ -218,14 +208,12 @@ int mi355rt_camera_get_ray(const mi355rt_handle* h, uint32_t u, uint32_t v, floa
 int mi355rt_set_seed(mi355rt_handle* h, uint64_t seed)
 {
     if (!h) return MI355RT_E_INVALID;
-    h->r->cfg.seed = seed;
-    return MI355RT_OK;
+    return h->r->set_seed(seed) ? MI355RT_OK : MI355RT_E_HIP;
 }
 int mi355rt_set_flags(mi355rt_handle* h, uint32_t flags)
 {
     if (!h) return MI355RT_E_INVALID;
-    h->r->cfg.flags = flags;
-    return MI355RT_OK;
+    return h->r->set_flags(flags) ? MI355RT_OK : MI355RT_E_INVALID;
 }
 
 int mi355rt_set_slices(mi355rt_handle* h, uint32_t slices)
@@ -263,6 +251,11 @@ int mi355rt_debug_numerics(mi355rt_handle* h, const float* a, const float* b, si
 {
     if (!h || (n && (!a || !b || !quot || !root || !pow32))) return MI355RT_E_INVALID;
     return h->r->debug_numerics(a, b, n, quot, root, pow32) ? MI355RT_OK : MI355RT_E_HIP;
+}
+int mi355rt_debug_slab(mi355rt_handle* h, const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin)
+{
+    if (!h || (n && (!inv_rays6 || !cubes6 || !hit || !tmin))) return MI355RT_E_INVALID;
+    return h->r->debug_slab(inv_rays6, cubes6, n, hit, tmin) ? MI355RT_OK : MI355RT_E_HIP;
 }
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h) { return h ? h->r->nodes_per_sample : 0u; }
 

@@ -60,6 +60,7 @@ struct DPass {
     size_t qstride;           // records per queue: a queue is three float4 planes q0[], q1[], q2[] (structure of arrays)
     uint32_t* hit_prim;       // per radiance record: triangle hit or 0xFFFFFFFF (the 16-byte hit record is written for hits only)
     uint32_t row0;
+    uint32_t row_wrap;        // entries of the cyclic row list (50-row frames: rows[(row0 + i) % row_wrap]); 0xFFFFFFFF: no wrap
     uint32_t npix;            // pixels in this pass (rows_in_pass * width)
     uint32_t nsamples;        // npix * samples per pixel in this pass
     uint32_t seed;
@@ -85,6 +86,7 @@ struct DCounters {            // one set per render call, zeroed at its start
     unsigned long long inner_execs, leaf_execs;   // COUNT mode: wave-level executions of the inner / leaf section
     unsigned int overflow;
     unsigned int pad;
+    unsigned long long primary_culled;            // primary samples in chunks the frustum culling skipped (never traced)
     unsigned long long t_first_end, t_last_end, t_sum_end, t_start, n_waves;   // COUNT mode: wave end times (s_memrealtime ticks, 100 MHz)
 };
 

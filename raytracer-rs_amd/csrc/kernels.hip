@@ -38,6 +38,10 @@ namespace mi355rt {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr uint32_t kMiss = 0xFFFFFFFFu;
+#ifndef MI355RT_FUSED_FENCE_AGENT
+#define MI355RT_FUSED_FENCE_AGENT 0
+#endif
+constexpr bool kFusedFenceAgent = MI355RT_FUSED_FENCE_AGENT != 0;      // A/B knob of the build (see phase_fence)
 constexpr int kInnerStepsPerIteration = 2;     // measured: 1 -> 2 takes 9 % off the trace kernel, 3 and 4 add nothing
 
 // One device word sustains only ~88 atomics/us on this chip: the statistics counters that every wave
@@ -119,6 +123,9 @@ __device__ __forceinline__ f3 fetch_texel(const DScene& sc, uint32_t tex, float 
 // primary rays of a wave are as coherent as they can be, and the chunk culling below tests compact tiles.
 // (The film does not depend on the order: every pixel accumulates its own samples in sample order.)
 constexpr uint32_t kRowGroup = 8u;
+// entry i of the pass's row list; the list is a cyclic window of ps.row_wrap entries when the pass is a 50-row
+// frame of trace_frame_additive (its rows are a run of the handle's device-resident owned-row list that may wrap)
+__device__ __forceinline__ uint32_t pass_row(const DPass& ps, uint32_t i) { return ps.rows[i >= ps.row_wrap ? i - ps.row_wrap : i]; }
 __device__ __forceinline__ void pass_column(const DPass& ps, uint32_t width, uint32_t p, uint32_t& first_row, uint32_t& nrows_in_group, uint32_t& x, uint32_t& y)
 {
     const uint32_t gs = width * kRowGroup, g = p / gs, q = p - g * gs;
@@ -131,7 +138,7 @@ __device__ __forceinline__ uint32_t pass_pixel(const DPass& ps, uint32_t width, 
 {
     uint32_t first_row, nr, x, y;
     pass_column(ps, width, p, first_row, nr, x, y);
-    return ps.rows[first_row + y] * width + x;
+    return pass_row(ps, first_row + y) * width + x;
 }
 
 // pixel -> primary ray, mod.rs:93-96 + camera.rs:80-90.  gi = index of the primary sample in the pass.
@@ -172,7 +179,7 @@ __device__ __forceinline__ bool chunk_is_culled(const DCamera& cam, const DPass&
     pass_column(ps, cam.width, g1 % ps.npix, fr1, nr1, xb, yb);
     if (fr0 != fr1) return false;                                    // straddles two row groups
     uint32_t row_lo = 0xFFFFFFFFu, row_hi = 0u;                      // all rows of the group (a superset of the chunk's)
-    for (uint32_t y = 0; y < nr0; ++y) { const uint32_t r = ps.rows[fr0 + y]; row_lo = min(row_lo, r); row_hi = max(row_hi, r); }
+    for (uint32_t y = 0; y < nr0; ++y) { const uint32_t r = pass_row(ps, fr0 + y); row_lo = min(row_lo, r); row_hi = max(row_hi, r); }
     const uint32_t ia = row_lo * cam.width + xa, ib = row_hi * cam.width + xb;
     const uint32_t va = (ps.flags & 1u) ? ia / cam.width : ia / cam.height, vb = (ps.flags & 1u) ? ib / cam.width : ib / cam.height;
     // same expressions as primary_sample with jitter 0 and 1 (monotonic in u, v), widened a little
@@ -196,15 +203,15 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
 }
 
 // ---- trace: closest hit of every ray of a round --------------------------------------------------
-template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
-                                                      const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
-                                                      float4* __restrict__ hits, uint32_t* cursor,
-                                                      float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
-                                                      DCounters* counters)
+// The trace loop of one wave.  SINGLE == false: persistent wave of trace_kernel, pulls chunks from `cursor`.
+// SINGLE == true: the wave traces exactly the rays of chunk `single_chunk` (fused_pass_kernel).
+template <bool PRIMARY, bool COUNT, bool SINGLE, bool STASH>
+__device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam, const DPass& ps,
+                                           const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                           float4* __restrict__ hits, uint32_t* cursor,
+                                           float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
+                                           DCounters* counters, int* stack, uint32_t single_chunk, uint32_t single_nrad, uint32_t single_nshadow)
 {
-    extern __shared__ int s_stack[];                 // ps.stack_depth rows of kBlock ints
-    int* stack = &s_stack[threadIdx.x];
     uint32_t acc_nodes = 0, acc_tris = 0, acc_ie = 0, acc_le = 0;
     unsigned long long t_begin = 0;
     if (COUNT) t_begin = __builtin_amdgcn_s_memrealtime();
@@ -231,7 +238,11 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene s
             if (w_next >= w_ntot) {
                 uint32_t c = 0u;
                 c = w_chunk;
-                if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c)) { exhausted = true; break; }
+                if (SINGLE) {
+                    if (!w_pull.first) { exhausted = true; break; }
+                    w_pull.first = false; c = single_chunk;
+                }
+                else if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c)) { exhausted = true; break; }
                 // bcast_first: these are wave-uniform by construction; saying so keeps them in SGPRs
                 w_chunk = bcast_first(c); w_next = 0u;
                 if (PRIMARY) {
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene s
                     w_nrad = bcast_first(w_nrad);
                     w_ntot = w_nrad;
                 }
+                else if (SINGLE) { w_nrad = single_nrad; w_ntot = single_nrad + single_nshadow; }      // from the shade phase, in registers
                 else { const uint2 n = in_counts[w_chunk]; w_nrad = bcast_first(n.x); w_ntot = w_nrad + bcast_first(n.y); }
                 continue;
             }
@@ -286,12 +298,12 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene s
 #pragma unroll
         for (int u = 0; u < kInnerStepsPerIteration; ++u) {
             if (__ballot(lane_at_inner(rs)) == 0ull) break;
-            inner_pred<COUNT>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_nodes);
+            inner_pred<COUNT, STASH>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_nodes);
             if (COUNT) ++acc_ie;
         }
-        const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
+        const unsigned long long m_leaf = __ballot(STASH ? lane_has_leaf_work(rs) : lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
-            { leaf_pred<COUNT>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_tris); if (COUNT) ++acc_le; }
+            { leaf_pred<COUNT, STASH>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_tris); if (COUNT) ++acc_le; }
         const bool fin = rs.node == kNodeFin;
         if (__ballot(fin) != 0ull) {
             if (fin) {
@@ -319,6 +331,17 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene s
             atomicAdd(&c0->t_sum_end, t_end - t_begin); atomicAdd(&c0->n_waves, 1ull);
         }
     }
+}
+
+template <bool PRIMARY, bool COUNT, bool STASH>
+__global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
+                                                      const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                                      float4* __restrict__ hits, uint32_t* cursor,
+                                                      float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
+                                                      DCounters* counters)
+{
+    extern __shared__ int s_stack[];                 // ps.stack_depth rows of kBlock ints
+    trace_wave<PRIMARY, COUNT, false, STASH>(sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters, &s_stack[threadIdx.x], 0u, 0u, 0u);
 }
 
 // ---- trace with the reference-exact octree intersector (parity path, MI355RT_FLAG_OCTREE_SEMANTICS) ----
@@ -360,26 +383,30 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
 }
 
 // ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
-template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
-                                                      const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
-                                                      const float4* __restrict__ hits,
-                                                      float4* __restrict__ out_q, uint2* __restrict__ out_counts,
-                                                      float* __restrict__ slot_L, uint32_t* __restrict__ sample_slot,
-                                                      const uint32_t* __restrict__ film_n, DCounters* counters)
-{
-    extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.list_cap hit indices
-    const int lane = lane_id();
-    uint32_t* list = &s_list[(threadIdx.x >> 6) * ps.list_cap];
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
-    unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
+// The wave's LDS list of hit indices: contiguous (shade_kernel) or spread over the wave's 64 columns of the
+// block's traversal-stack rows (fused_pass_kernel, where the same LDS serves both phases).
+struct LinearList { uint32_t* p; __device__ __forceinline__ uint32_t& operator[](uint32_t i) const { return p[i]; } };
+struct ColumnList { int* col0; __device__ __forceinline__ uint32_t& operator[](uint32_t i) const { return *(uint32_t*)&col0[(i >> 6) * kBlock + (i & 63u)]; } };
 
-    for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
-        uint32_t n_rad = PRIMARY ? min(ps.chunk, ps.nsamples - chunk * ps.chunk) : in_counts[chunk].x;
+// Shade the hits of one chunk (one wave): see the header of this file.
+// in_nrad: radiance rays of the chunk in in_q (ignored for PRIMARY); out_nrad / out_nshadow: what was appended to out_q.
+template <bool PRIMARY, class List>
+__device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level, uint32_t chunk, const List list,
+                                            const float4* __restrict__ in_q, uint32_t in_nrad, uint32_t& out_nrad, uint32_t& out_nshadow,
+                                            const float4* __restrict__ hits,
+                                            float4* __restrict__ out_q, uint2* __restrict__ out_counts,
+                                            float* __restrict__ slot_L, uint32_t* __restrict__ sample_slot,
+                                            const uint32_t* __restrict__ film_n, DCounters* counters,
+                                            unsigned long long& acc_bounce, unsigned long long& acc_shadow, unsigned long long& acc_hits)
+{
+    const int lane = lane_id();
+    {
+        uint32_t n_rad = PRIMARY ? min(ps.chunk, ps.nsamples - chunk * ps.chunk) : in_nrad;
         const size_t base = (size_t)chunk * ps.region;
         if (PRIMARY && chunk_is_culled(cam, ps, chunk, n_rad)) {
             // no hit records were written for this chunk: every sample is a miss
             for (uint32_t i = (uint32_t)lane; i < n_rad; i += 64u) sample_slot[chunk * ps.chunk + i] = kMiss;
+            acc_hits += (unsigned long long)n_rad << 32;         // high half: primary samples skipped by the frustum culling
             n_rad = 0u;
         }
         // ---- compact the rays that hit something (wave64 ballot + prefix popcount into LDS)
@@ -512,14 +539,39 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene s
         __builtin_amdgcn_wave_barrier();
         if (out_front + out_back > ps.region) { if (lane == 0) counters->overflow = 1u; out_front = 0u; out_back = 0u; }
         if (lane == 0) out_counts[chunk] = make_uint2(out_front, out_back);
+        out_nrad = out_front; out_nshadow = out_back;
         acc_bounce += out_front; acc_shadow += out_back; acc_hits += cnt;
     }
-    if (lane == 0) {
+}
+
+__device__ __forceinline__ void flush_shade_counters(DCounters* counters, uint32_t wave, unsigned long long acc_bounce, unsigned long long acc_shadow, unsigned long long acc_hits)
+{
+    if (lane_id() == 0) {
         DCounters* cs = &counters[wave % kShards];
         if (acc_bounce) atomicAdd(&cs->bounce, acc_bounce);
         if (acc_shadow) atomicAdd(&cs->shadow, acc_shadow);
-        if (PRIMARY && acc_hits) atomicAdd(&cs->primary_hits, acc_hits);
+        if (acc_hits & 0xFFFFFFFFull) atomicAdd(&cs->primary_hits, acc_hits & 0xFFFFFFFFull);
+        if (acc_hits >> 32) atomicAdd(&cs->primary_culled, acc_hits >> 32);
     }
+}
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
+                                                      const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                                      const float4* __restrict__ hits,
+                                                      float4* __restrict__ out_q, uint2* __restrict__ out_counts,
+                                                      float* __restrict__ slot_L, uint32_t* __restrict__ sample_slot,
+                                                      const uint32_t* __restrict__ film_n, DCounters* counters)
+{
+    extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.list_cap hit indices
+    const LinearList list{ &s_list[(threadIdx.x >> 6) * ps.list_cap] };
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+    unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
+    for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
+        uint32_t o_rad, o_sh;
+        shade_chunk<PRIMARY>(sc, cam, ps, level, chunk, list, in_q, PRIMARY ? 0u : in_counts[chunk].x, o_rad, o_sh, hits, out_q, out_counts, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
+    }
+    flush_shade_counters(counters, wave, acc_bounce, acc_shadow, PRIMARY ? acc_hits : 0ull);
 }
 
 // ---- resolve: radiance tree -> sample colour -> film ------------------------------------------
@@ -596,6 +648,83 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
     }
 }
 
+// ---- one 50-row frame in ONE launch (trace_frame_additive, mod.rs:80-117) ---------------------------------
+// A call of the reference's entry traces 50 rows x 1 sample: ~51 k primary samples at the reference binary's
+// 1024x768, a few microseconds of work for this chip.  As wavefront rounds that is 8 dependent launches of a
+// persistent grid: launch latency and drain, nothing else.  Here every wave takes a chunk of 64 samples (an 8x8
+// pixel tile) through ALL rounds by itself — trace, shade, trace, ... , resolve — with the same device functions,
+// the same queue regions (its chunk's, in global memory) and therefore the same arithmetic as the wavefront
+// kernels; between phases a fence makes the wave's own stores visible to its loads.  No cursor, no memset, no
+// inter-wave dependency; samples per pixel in such a pass is 1 (film.rs:20-24: one add per pixel).
+// The wave reads back only what IT stored (its chunk's queue region, hit records, light terms): the stores must have
+// left the wave (vmcnt) and the loads must not be served from a stale line of this CU's vector cache.  WORKGROUP scope
+// is exactly that on gfx950 (the waves of a workgroup share the CU's cache, which stores write through): a wait, no
+// L2 write-back / invalidate.  An agent-scope fence here flushes and invalidates the XCD's whole L2 eight times per
+// wave — it made this kernel 3.5x slower (0.35 ms -> see profiles/r02_notes.md), evicting the BVH each time.
+__device__ __forceinline__ void phase_fence()
+{
+    if (kFusedFenceAgent) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+__device__ __forceinline__ void resolve_chunk_1spp(const DPass& ps, uint32_t width, uint32_t nlights, uint32_t chunk, const float* slot_L, const uint32_t* sample_slot,
+                                                   float* film_sum, float* film_sumsq, uint32_t* film_n)
+{
+    const uint32_t n = min(ps.chunk, ps.nsamples - chunk * ps.chunk);
+    for (uint32_t i = (uint32_t)lane_id(); i < n; i += 64u) {
+        const uint32_t p = chunk * ps.chunk + i;                         // 1 sample per pixel: sample index == pixel index of the pass
+        const uint32_t pixel = pass_pixel(ps, width, p);
+        const uint32_t sl = sample_slot[p];
+        const float* L = slot_L + 3ull * ((size_t)sl * ps.nodes_per_sample * nlights);
+        f3 c = mk3(0.0f, 0.0f, 0.0f);                                    // primary miss: RGB::black(), mod.rs:100
+        if (sl != 0xFFFFFFFFu) switch (ps.recursions) {
+            case 0: c = node_radiance<0>(L, ps, nlights, 0, 0); break;
+            case 1: c = node_radiance<1>(L, ps, nlights, 0, 0); break;
+            case 2: c = node_radiance<2>(L, ps, nlights, 0, 0); break;
+            default: c = node_radiance<3>(L, ps, nlights, 0, 0); break;
+        }
+        // PixelData::add_sample, film.rs:20-24
+        float* ps_ = film_sum + 3ull * pixel; float* pq = film_sumsq + 3ull * pixel;
+        ps_[0] = ps_[0] + c.x; ps_[1] = ps_[1] + c.y; ps_[2] = ps_[2] + c.z;
+        pq[0] = pq[0] + c.x * c.x; pq[1] = pq[1] + c.y * c.y; pq[2] = pq[2] + c.z * c.z;
+        film_n[pixel] = film_n[pixel] + 1u;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera cam, DPass ps, float4* q0, float4* q1, uint2* c0, uint2* c1,
+                                                            float4* hits, float* slot_L, uint32_t* sample_slot,
+                                                            float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters)
+{
+    extern __shared__ int s_stack[];                 // max(traversal stack rows, hit-list rows) x kBlock ints
+    int* stack = &s_stack[threadIdx.x];
+    const ColumnList list{ &s_stack[threadIdx.x & ~63u] };
+    const uint32_t wave = global_wave_id(), nwaves = gridDim.x * kWavesPerBlock;
+    unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
+    for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
+        // ray counts of the chunk travel from phase to phase in registers: a wave-uniform load of the count the wave
+        // itself stored a moment ago would go through the scalar cache, which may hold the line from a neighbour's read
+        uint32_t n_rad = 0u, n_sh = 0u;
+        trace_wave<true, false, true, false>(sc, cam, ps, nullptr, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, 0u, 0u);
+        phase_fence();
+        shade_chunk<true>(sc, cam, ps, 0u, chunk, list, nullptr, 0u, n_rad, n_sh, hits, q0, c0, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
+        phase_fence();
+        for (uint32_t r = 1; r < ps.recursions + 2u; ++r) {
+            float4* in_q = (r - 1u) & 1u ? q1 : q0;
+            trace_wave<false, false, true, false>(sc, cam, ps, in_q, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, n_rad, n_sh);
+            phase_fence();
+            if (r <= ps.recursions) {
+                unsigned long long unused = 0;
+                uint32_t o_rad = 0u, o_sh = 0u;
+                shade_chunk<false>(sc, cam, ps, r, chunk, list, in_q, n_rad, o_rad, o_sh, hits, r & 1u ? q1 : q0, r & 1u ? c1 : c0, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, unused);
+                n_rad = o_rad; n_sh = o_sh;
+                phase_fence();
+            }
+        }
+        resolve_chunk_1spp(ps, cam.width, sc.nlights, chunk, slot_L, sample_slot, film_sum, film_sumsq, film_n);
+    }
+    flush_shade_counters(counters, wave, acc_bounce, acc_shadow, acc_hits);
+}
+
 // ---- get_tonemapped_pixels, mod.rs:120-128 = film.rs:43-47 + tonemap.rs:4-10 + color.rs:85-95 --
 __device__ __forceinline__ uint32_t to_u8(float c)
 {
@@ -603,13 +732,13 @@ __device__ __forceinline__ uint32_t to_u8(float c)
     const float m = fmaxf(fminf(c, 1.0f), 0.0f) * 255.0f;
     return (uint32_t)m & 0xFFu;
 }
-__global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ rows, uint32_t nrows, uint32_t width, int packed,
+__global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict__ rows, uint32_t row_base, uint32_t nrows, uint32_t width, int packed,
                                                      const float* __restrict__ film_sum, const uint32_t* __restrict__ film_n, uint32_t* out)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nrows * width) return;
     const uint32_t r = (uint32_t)(i / width), x = (uint32_t)(i % width);
-    const size_t pixel = (size_t)rows[r] * width + x;
+    const size_t pixel = (size_t)(rows ? rows[r] : row_base + r) * width + x;      // rows == null: the rows row_base .. row_base + nrows - 1
     const float inv = div_rn(1.0f, (float)film_n[pixel]);                     // film.rs:46
     const float cr = film_sum[3 * pixel] * inv, cg = film_sum[3 * pixel + 1] * inv, cb = film_sum[3 * pixel + 2] * inv;
     const uint32_t R = to_u8(div_rn(cr, 1.0f + cr)), G = to_u8(div_rn(cg, 1.0f + cg)), B = to_u8(div_rn(cb, 1.0f + cb));
@@ -655,6 +784,49 @@ __global__ void numerics_kernel(const float* __restrict__ a, const float* __rest
     r[i] = sqrt_rn(a[i]);
     p[i] = pow32(a[i]);
 }
+// ---- the reference's slab test as the device runs it (known-answer vectors of oct_tree_intersector.rs:475-512) ----
+__global__ void slab_kernel(const float* __restrict__ inv_rays6, const float* __restrict__ cubes6, uint32_t n, uint8_t* hit, float* tmin)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = inv_rays6 + 6ull * i; const float* c = cubes6 + 6ull * i;
+    float t = 0.0f;
+    const bool h = cube_slab(mk3(c[0], c[1], c[2]), mk3(c[3], c[4], c[5]), mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), t);
+    hit[i] = h ? 1 : 0; tmin[i] = t;
+}
+hipError_t launch_slab(hipStream_t stream, const float* inv_rays6, const float* cubes6, uint32_t n, uint8_t* hit, float* tmin)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(slab_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, inv_rays6, cubes6, n, hit, tmin);
+    return hipGetLastError();
+}
+
+// ---- Film::get_pixels (film.rs:43-47) and Film::get_estimated_variances (film.rs:51-67) on the device ----
+__global__ __launch_bounds__(256) void film_stat_kernel(int variances, size_t npix, const float* __restrict__ film_sum, const float* __restrict__ film_sumsq,
+                                                       const uint32_t* __restrict__ film_n, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t n = film_n[i];
+    if (!variances) {
+        const float inv = div_rn(1.0f, (float)n);                                   // film.rs:46
+        out[3 * i] = film_sum[3 * i] * inv; out[3 * i + 1] = film_sum[3 * i + 1] * inv; out[3 * i + 2] = film_sum[3 * i + 2] * inv;
+        return;
+    }
+    const float nn1 = (float)(uint32_t)(n * (n - 1u));                              // film.rs:55-56 (u32 product)
+    const float n2n1 = (float)n * nn1;                                              // film.rs:57
+    for (int c = 0; c < 3; ++c) {
+        const float s = film_sum[3 * i + c], q = film_sumsq[3 * i + c];
+        out[3 * i + c] = (div_rn(q, nn1) - div_rn(s * s, n2n1)) * 50.0f;            // film.rs:58-64
+    }
+}
+hipError_t launch_film_stat(hipStream_t stream, bool variances, size_t npix, const float* film_sum, const float* film_sumsq, const uint32_t* film_n, float* out)
+{
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(film_stat_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, variances ? 1 : 0, npix, film_sum, film_sumsq, film_n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, uint32_t n, float* q, float* r, float* p)
 {
     if (n == 0) return hipSuccess;
@@ -665,7 +837,7 @@ hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, u
 // ---- launchers --------------------------------------------------------------------------------
 static size_t stack_bytes(uint32_t depth) { return (size_t)((depth ? depth : 1u) + 1u) * kBlock * sizeof(int); }   // + one trash row
 
-template <bool P, bool C>
+template <bool P, bool C, bool S>
 static int trace_blocks_per_cu(size_t lds)
 {
     // the occupancy query costs ~0.3 ms of host time: ask once per (kernel, LDS size)
@@ -673,33 +845,39 @@ static int trace_blocks_per_cu(size_t lds)
     static int cached_nb = 0;
     if (cached_lds != lds) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<P, C>, kBlock, lds) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<P, C, S>, kBlock, lds) != hipSuccess || nb < 1) nb = 1;
         cached_nb = nb > 8 ? 8 : nb;
         cached_lds = lds;
     }
     return cached_nb;
 }
 
-hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, const DScene& sc, const DCamera& cam, const DPass& ps,
-                        const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
-                        float* slot_L, const uint32_t* film_n, DCounters* counters)
+template <bool P, bool C, bool S>
+static hipError_t launch_trace_variant(hipStream_t stream, int num_cus, const DScene& sc, const DCamera& cam, const DPass& ps,
+                                       const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
+                                       float* slot_L, const uint32_t* film_n, DCounters* counters)
 {
     // persistent grid: as many blocks as the chip holds; waves pull chunks from `cursor`
     const size_t lds = stack_bytes(ps.stack_depth);
-    const int per_cu = primary ? (count ? trace_blocks_per_cu<true, true>(lds) : trace_blocks_per_cu<true, false>(lds))
-                               : (count ? trace_blocks_per_cu<false, true>(lds) : trace_blocks_per_cu<false, false>(lds));
+    const int per_cu = trace_blocks_per_cu<P, C, S>(lds);
     int use_per_cu = per_cu;
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= per_cu) use_per_cu = v; }   // occupancy experiment
-    dim3 grid((unsigned)(num_cus * use_per_cu)), block(kBlock);
-    const float4* iq = (const float4*)in_q; const uint2* ic = (const uint2*)in_counts; float4* hq = (float4*)hits;
-    if (primary) {
-        if (count) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
-    } else {
-        if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, stream, sc, cam, ps, iq, ic, hq, cursor, slot_L, film_n, counters);
-    }
+    hipLaunchKernelGGL((trace_kernel<P, C, S>), dim3((unsigned)(num_cus * use_per_cu)), dim3(kBlock), lds, stream, sc, cam, ps,
+                       (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n, counters);
     return hipGetLastError();
+}
+
+hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, bool stash, const DScene& sc, const DCamera& cam, const DPass& ps,
+                        const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
+                        float* slot_L, const uint32_t* film_n, DCounters* counters)
+{
+#define MI355RT_TRACE_CASE(P, C, S) if (primary == P && count == C && stash == S) return launch_trace_variant<P, C, S>(stream, num_cus, sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters)
+    MI355RT_TRACE_CASE(true, false, false); MI355RT_TRACE_CASE(false, false, false);
+    MI355RT_TRACE_CASE(true, true, false); MI355RT_TRACE_CASE(false, true, false);
+    MI355RT_TRACE_CASE(true, false, true); MI355RT_TRACE_CASE(false, false, true);
+    MI355RT_TRACE_CASE(true, true, true); MI355RT_TRACE_CASE(false, true, true);
+#undef MI355RT_TRACE_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
@@ -740,13 +918,34 @@ hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, u
     return hipGetLastError();
 }
 
-hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t nrows, uint32_t width, bool packed,
+hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t row_base, uint32_t nrows, uint32_t width, bool packed,
                           const float* film_sum, const uint32_t* film_n, uint32_t* out)
 {
     const size_t n = (size_t)nrows * width;
     if (n == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL(tonemap_kernel, grid, block, 0, stream, rows, nrows, width, packed ? 1 : 0, film_sum, film_n, out);
+    hipLaunchKernelGGL(tonemap_kernel, grid, block, 0, stream, rows, row_base, nrows, width, packed ? 1 : 0, film_sum, film_n, out);
+    return hipGetLastError();
+}
+
+// rows of LDS the fused kernel needs: the traversal stack (+ trash row) or the wave's hit list, whichever is larger
+uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes)
+{
+    const uint32_t a = (stack_depth ? stack_depth : 1u) + 1u;
+    return a > max_level_nodes ? a : max_level_nodes;
+}
+
+hipError_t launch_fused_pass(hipStream_t stream, int num_cus, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes,
+                             void* q0, void* q1, void* c0, void* c1, void* hits, float* slot_L, uint32_t* sample_slot,
+                             float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters)
+{
+    if (ps.nchunks == 0) return hipSuccess;
+    const size_t lds = (size_t)fused_pass_lds_rows(ps.stack_depth, max_level_nodes) * kBlock * sizeof(int);
+    unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned cap = (unsigned)num_cus * 8u;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(fused_pass_kernel, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1, (uint2*)c0, (uint2*)c1,
+                       (float4*)hits, slot_L, sample_slot, film_sum, film_sumsq, film_n, counters);
     return hipGetLastError();
 }
 

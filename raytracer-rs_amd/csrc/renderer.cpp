@@ -55,6 +55,47 @@ std::unique_ptr<Renderer> Renderer::create(const SceneData& scene, const mi355rt
     return r;
 }
 
+// SampleGenerator::new, sample_generator.rs:15-24 + 36-52, seeded: 65 536 unit vectors by rejection in the unit ball
+void Renderer::build_sample_table(std::vector<float>& table4)
+{
+    table.resize((size_t)kNumSamples * 3);
+    table4.assign((size_t)kNumSamples * 4, 0.0f);
+    for (uint32_t i = 0; i < kNumSamples; ++i) {
+        for (uint32_t attempt = 0;; ++attempt) {
+            uint32_t h[4] = { i, attempt, 0xFFFFFFFFu, (uint32_t)cfg.seed };
+            pcg4d(h);
+            Vec3 d(u01(h[0]) * 2.0f + -1.0f, u01(h[1]) * 2.0f + -1.0f, u01(h[2]) * 2.0f + -1.0f);   // random_range(-1.0..1.0)
+            if (dot(d, d) < 1.0f) {
+                Vec3 nrm = d.normalized();
+                table[3 * (size_t)i] = nrm.x; table[3 * (size_t)i + 1] = nrm.y; table[3 * (size_t)i + 2] = nrm.z;
+                table4[4 * (size_t)i] = nrm.x; table4[4 * (size_t)i + 1] = nrm.y; table4[4 * (size_t)i + 2] = nrm.z;
+                break;
+            }
+        }
+    }
+}
+
+// mi355rt_set_seed: the handle afterwards equals one created with this seed (per-sample hash key AND direction table)
+bool Renderer::set_seed(uint64_t seed)
+{
+    if (!bind()) return false;
+    cfg.seed = seed;
+    std::vector<float> table4;
+    build_sample_table(table4);
+    for (Slice& o : slices_) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
+    HIP_TRY(hipMemcpy(const_cast<void*>(dscene_.table), table4.data(), table4.size() * sizeof(float), hipMemcpyHostToDevice));
+    return true;
+}
+
+// mi355rt_set_flags: run-time flags only; a create-time flag (the intersector) cannot be changed on a live handle
+bool Renderer::set_flags(uint32_t flags)
+{
+    constexpr uint32_t kCreateMask = MI355RT_FLAG_OCTREE_SEMANTICS;
+    if ((flags ^ cfg.flags) & kCreateMask) { last_error = "MI355RT_FLAG_OCTREE_SEMANTICS is a create-time flag: it cannot be changed with mi355rt_set_flags"; return false; }
+    cfg.flags = flags;
+    return true;
+}
+
 bool Renderer::init(const SceneData& scene, std::string& err, int& code)
 {
     code = MI355RT_E_INVALID;
@@ -112,22 +153,8 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
         uint32_t g = scene.tri_geom[t];
         std::memcpy(&normals[4 * (size_t)t + 3], &g, 4);
     }
-    // --- SampleGenerator::new, sample_generator.rs:15-24 + 36-52, seeded
-    table.resize((size_t)kNumSamples * 3);
-    std::vector<float> table4((size_t)kNumSamples * 4, 0.0f);
-    for (uint32_t i = 0; i < kNumSamples; ++i) {
-        for (uint32_t attempt = 0;; ++attempt) {
-            uint32_t h[4] = { i, attempt, 0xFFFFFFFFu, (uint32_t)cfg.seed };
-            pcg4d(h);
-            Vec3 d(u01(h[0]) * 2.0f + -1.0f, u01(h[1]) * 2.0f + -1.0f, u01(h[2]) * 2.0f + -1.0f);   // random_range(-1.0..1.0)
-            if (dot(d, d) < 1.0f) {
-                Vec3 nrm = d.normalized();
-                table[3 * (size_t)i] = nrm.x; table[3 * (size_t)i + 1] = nrm.y; table[3 * (size_t)i + 2] = nrm.z;
-                table4[4 * (size_t)i] = nrm.x; table4[4 * (size_t)i + 1] = nrm.y; table4[4 * (size_t)i + 2] = nrm.z;
-                break;
-            }
-        }
-    }
+    std::vector<float> table4;
+    build_sample_table(table4);
     // --- uploads
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_normals = nullptr; void* d_table = nullptr;
     DMaterial* d_mats = nullptr; DLight* d_lights = nullptr; DTexture* d_tex = nullptr; float* d_texels = nullptr;
@@ -185,6 +212,8 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     const size_t npix = (size_t)cfg.width * cfg.height;
     if (!upload(d_film_sum_, nullptr, npix * 12) || !upload(d_film_sumsq_, nullptr, npix * 12) || !upload(d_film_n_, nullptr, npix * 4)) return bail();
     if (!upload(d_ldr_, nullptr, npix * 4)) return bail();
+    ldr_dirty_.assign(cfg.height, (uint8_t)1);
+    if (hipEventCreateWithFlags(&ev_tonemap_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
     std::vector<uint32_t> all(cfg.height);
     for (uint32_t r = 0; r < cfg.height; ++r) {
         all[r] = r;
@@ -215,6 +244,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     for (uint32_t l = 0; l <= cfg.recursions; ++l) max_level_nodes_ = std::max(max_level_nodes_, level_first[l + 1] - level_first[l]);
     chunk_ = 256;
     if (const char* e = getenv("MI355RT_LEAF_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) leaf_threshold_ = (uint32_t)v; }
+    if (const char* e = getenv("MI355RT_STASH")) stash_ = atoi(e) != 0;
     if (const char* e = getenv("MI355RT_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) chunk_ = (uint32_t)v; }
     code = MI355RT_OK;
     return true;
@@ -229,6 +259,8 @@ Renderer::~Renderer()
         if (slices_[i].done) (void)hipEventDestroy(slices_[i].done);
     }
     for (void* p : allocs_) (void)hipFree(p);
+    if (h_ldr_) (void)hipHostFree(h_ldr_);
+    if (ev_tonemap_) (void)hipEventDestroy(ev_tonemap_);
     free_pass_buffers();
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
@@ -392,28 +424,36 @@ bool Renderer::assign_slice_rows(uint32_t nslices)
 }
 
 // One wavefront pass: `nrows` rows starting at d_rows[row0], spp samples per pixel.
-bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample)
+// Fill the pass descriptor shared by the wavefront kernels and the fused kernel.
+void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t row_wrap, uint32_t npix, size_t nsamples, uint32_t chunk,
+                             bool explicit_sample, uint32_t epixel, uint32_t esample) const
+{
+    ps = DPass{};
+    ps.rows = d_rows; ps.row0 = row0; ps.row_wrap = row_wrap; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
+    ps.seed = (uint32_t)cfg.seed; ps.flags = cfg.flags; ps.recursions = cfg.recursions; ps.spread = cfg.spread;
+    ps.nodes_per_sample = nodes_per_sample;
+    std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
+    ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
+    ps.chunk = chunk; ps.nchunks = (uint32_t)((nsamples + chunk - 1) / chunk); ps.region = chunk * records_per_sample_;
+    ps.hit_prim = sl.d_hit_prim; ps.qstride = sl.queue_records;
+    ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk * max_level_nodes_;
+    ps.leaf_threshold = leaf_threshold_;
+    ps.refill_threshold = 24; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
+    ps.pull_mode = 4u;                  // 64 interleaved cursors (see pull_chunk in kernels.hip)
+    if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
+    ps.pull_group = 1; if (const char* e = getenv("MI355RT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.pull_group = (uint32_t)v; }
+    ps.ncursors = 64; if (const char* e = getenv("MI355RT_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxCursors) ps.ncursors = (uint32_t)v; }
+}
+
+bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample, uint32_t row_wrap)
 {
     const uint32_t npix = explicit_sample ? 1u : nrows * cfg.width;
     const size_t nsamples = (size_t)npix * spp;
     if (nsamples == 0) return true;
     if (!ensure_pass_capacity(sl, nsamples)) return false;
     hipStream_t st = sl.stream;             // every launch of this pass goes to the slice's stream
-    DPass ps{};
-    ps.rows = d_rows; ps.row0 = row0; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
-    ps.seed = (uint32_t)cfg.seed; ps.flags = cfg.flags; ps.recursions = cfg.recursions; ps.spread = cfg.spread;
-    ps.nodes_per_sample = nodes_per_sample;
-    std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
-    ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
-    ps.chunk = chunk_; ps.nchunks = (uint32_t)((nsamples + chunk_ - 1) / chunk_); ps.region = chunk_ * records_per_sample_;
-    ps.hit_prim = sl.d_hit_prim; ps.qstride = sl.queue_records;
-    ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk_ * max_level_nodes_;
-    ps.leaf_threshold = leaf_threshold_;
-    ps.refill_threshold = 24; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
-    ps.pull_mode = 4u;                  // 8 interleaved cursors (see pull_chunk in kernels.hip)
-    if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
-    ps.pull_group = 1; if (const char* e = getenv("MI355RT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.pull_group = (uint32_t)v; }
-    ps.ncursors = 64; if (const char* e = getenv("MI355RT_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxCursors) ps.ncursors = (uint32_t)v; }
+    DPass ps;
+    describe_pass(ps, sl, d_rows, row0, row_wrap, npix, nsamples, chunk_, explicit_sample, epixel, esample);
     const DCamera cam = device_camera();
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
     const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
@@ -440,7 +480,7 @@ bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32
         if (dscene_.oct_nodes)
             HIP_TRY(launch_trace_octree(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
         else
-            HIP_TRY(launch_trace(st, num_cus_, r == 0, count, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
+            HIP_TRY(launch_trace(st, num_cus_, r == 0, count, stash_, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], st)); ev_used_ += 2; }
         ++launches_;
         if (balance_dbg) {
@@ -462,9 +502,41 @@ bool Renderer::begin_call()
 {
     if (!bind()) return false;
     ev_used_ = 0; launches_ = 0;
+    counts_pending_ = false;
     HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
     HIP_TRY(hipEventRecord(ev_begin_, stream_));
     active_slices_ = 1;
+    return true;
+}
+
+// Download the device counters of the call that just ended (the stream must be idle).
+bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
+{
+    DCounters shard[kShards], c{};
+    HIP_TRY(hipMemcpy(shard, d_counters_, sizeof shard, hipMemcpyDeviceToHost));
+    for (const DCounters& s : shard) {
+        c.bounce += s.bounce; c.shadow += s.shadow; c.primary_hits += s.primary_hits;
+        c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
+        c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs; c.primary_culled += s.primary_culled;
+    }
+    counts = mi355rt_ray_counts{};
+    counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
+    counts.nodes_visited = c.nodes_visited; counts.tris_tested = c.tris_tested; counts.trace_launches = launches_;
+    counts.inner_execs = c.inner_execs; counts.leaf_execs = c.leaf_execs; counts.primary_culled = c.primary_culled;
+    if (getenv("MI355RT_DEBUG_UTIL")) fprintf(stderr, "[mi355rt] inner execs %llu (lane util %.3f) leaf execs %llu (lane util %.3f)\n", c.inner_execs, c.inner_execs ? (double)c.nodes_visited / (64.0 * c.inner_execs) : 0.0, c.leaf_execs, c.leaf_execs ? (double)c.tris_tested / (64.0 * c.leaf_execs) : 0.0);
+    if (timed_call) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+        counts.total_ms = ms;
+    }
+    double tms = 0.0;
+    for (size_t i = 0; i + 1 < ev_used_; i += 2) {           // MI355RT_FLAG_TIME_KERNELS: events around every trace / fused launch
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, ev_pool_[i], ev_pool_[i + 1]));
+        tms += t;
+    }
+    counts.trace_ms = tms;
+    if (c.overflow) { last_error = "internal: ray queue overflow"; return false; }
     return true;
 }
 
@@ -477,53 +549,93 @@ bool Renderer::end_call(uint64_t primary)
     active_slices_ = 1;
     HIP_TRY(hipEventRecord(ev_end_, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
-    DCounters shard[kShards], c{};
-    HIP_TRY(hipMemcpy(shard, d_counters_, sizeof shard, hipMemcpyDeviceToHost));
-    for (const DCounters& s : shard) {
-        c.bounce += s.bounce; c.shadow += s.shadow; c.primary_hits += s.primary_hits;
-        c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
-        c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs;
+    return fetch_counts(primary, true);
+}
+
+// Counters of the last call.  A 50-row frame (trace_frame_additive) returns without waiting for the device;
+// its counters are fetched when somebody asks for them.
+bool Renderer::last_counts(mi355rt_ray_counts& out)
+{
+    if (counts_pending_) {
+        if (!bind()) return false;
+        HIP_TRY(hipStreamSynchronize(stream_));
+        counts_pending_ = false;
+        if (!fetch_counts(pending_primary_, false)) return false;
     }
-    counts = mi355rt_ray_counts{};
-    counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
-    counts.nodes_visited = c.nodes_visited; counts.tris_tested = c.tris_tested; counts.trace_launches = launches_;
-    if (getenv("MI355RT_DEBUG_UTIL")) fprintf(stderr, "[mi355rt] inner execs %llu (lane util %.3f) leaf execs %llu (lane util %.3f)\n", c.inner_execs, c.inner_execs ? (double)c.nodes_visited / (64.0 * c.inner_execs) : 0.0, c.leaf_execs, c.leaf_execs ? (double)c.tris_tested / (64.0 * c.leaf_execs) : 0.0);
-    float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
-    counts.total_ms = ms;
-    double tms = 0.0;
-    for (size_t i = 0; i + 1 < ev_used_; i += 2) {
-        float t = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&t, ev_pool_[i], ev_pool_[i + 1]));
-        tms += t;
-    }
-    counts.trace_ms = tms;
-    if (c.overflow) { last_error = "internal: ray queue overflow"; return false; }
+    out = counts;
     return true;
+}
+
+// The 50-row window of one trace_frame_additive call (mod.rs:87,114) as runs of the device-resident owned-row
+// list: entry i of run k is owned_rows[(first + i) % owned], and no row occurs twice inside a run (a row can
+// occur more than once per call only when height < 50; each occurrence must see the previous one's film update).
+struct FrameWindow { uint32_t first = 0, total = 0, next_row = 0; };
+static FrameWindow frame_window(uint32_t current_row, uint32_t height, uint32_t stripe_rows, uint32_t world, uint32_t rank, const std::vector<uint32_t>& owned)
+{
+    FrameWindow w;
+    uint32_t row = current_row;
+    bool have_first = false;
+    for (int k = 0; k < 50; ++k) {
+        if ((row / stripe_rows) % world == rank) {
+            if (!have_first) { w.first = (uint32_t)(std::lower_bound(owned.begin(), owned.end(), row) - owned.begin()); have_first = true; }
+            ++w.total;
+        }
+        row = (row + 1) % height;
+    }
+    w.next_row = row;
+    return w;
+}
+
+void Renderer::mark_dirty_window(uint32_t first, uint32_t total)
+{
+    const uint32_t nown = (uint32_t)owned_rows.size();
+    for (uint32_t i = 0; i < total && i < nown; ++i) ldr_dirty_[owned_rows[(first + i) % nown]] = 1;
 }
 
 uint32_t Renderer::trace_frame_additive()
 {
-    if (!begin_call()) return 0;
-    // 50 rows from the row cursor, wrapping modulo height (mod.rs:87,114); with stripes only owned rows are traced
-    std::vector<uint32_t> rows;
-    uint32_t row = current_row;
-    for (int k = 0; k < 50; ++k) {
-        if ((row / cfg.stripe_rows) % cfg.stripe_world == cfg.stripe_rank) rows.push_back(row);
-        row = (row + 1) % cfg.height;
+    const uint32_t nown = (uint32_t)owned_rows.size();
+    const FrameWindow win = frame_window(current_row, cfg.height, cfg.stripe_rows, cfg.stripe_world, cfg.stripe_rank, owned_rows);
+    // instrumented / timed / reference-exact-octree calls go through the wavefront rounds (several launches, waits for the device)
+    const bool wavefront = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0 || dscene_.oct_nodes != nullptr
+                           || fused_pass_lds_rows(bvh.max_depth + 1, max_level_nodes_) > 60u || getenv("MI355RT_NO_FUSED");
+    if (wavefront) {
+        if (!begin_call()) return 0;
+        for (uint32_t done = 0; done < win.total; done += nown) {
+            const uint32_t n = std::min(nown, win.total - done);
+            if (!run_pass(slices_[0], d_owned_rows_, (win.first + done) % nown, n, 1, false, 0, 0, nown)) return 0;
+        }
+        current_row = win.next_row;
+        mark_dirty_window(win.first, win.total);
+        if (!end_call((uint64_t)win.total * cfg.width)) return 0;
+        return 50u * cfg.width;
     }
-    // a row can appear more than once when height < 50: each occurrence is its own 1-sample pass segment
-    size_t start = 0;
-    while (start < rows.size()) {
-        size_t end = start + 1;
-        while (end < rows.size() && std::find(rows.begin() + start, rows.begin() + end, rows[end]) == rows.begin() + end) ++end;
-        if (hipMemcpyAsync(d_tmp_rows_, rows.data() + start, (end - start) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "row upload failed"; return 0; }
-        if (hipStreamSynchronize(stream_) != hipSuccess) { last_error = "stream sync failed"; return 0; }
-        if (!run_pass(slices_[0], d_tmp_rows_, 0, (uint32_t)(end - start), 1, false, 0, 0)) return 0;
-        start = end;
+    // fast path: one launch per run, nothing uploaded, nothing waited for
+    if (!bind()) return 0;
+    ev_used_ = 0; launches_ = 0;
+    if (hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_) != hipSuccess) { last_error = "hipMemsetAsync failed"; return 0; }
+    Slice& sl = slices_[0];
+    const DCamera cam = device_camera();
+    for (uint32_t done = 0; done < win.total; done += nown) {
+        const uint32_t n = std::min(nown, win.total - done);
+        const size_t nsamples = (size_t)n * cfg.width;
+        if (!ensure_pass_capacity(sl, nsamples)) return 0;
+        DPass ps;
+        describe_pass(ps, sl, d_owned_rows_, (win.first + done) % nown, nown, (uint32_t)nsamples, nsamples, 64u, false, 0, 0);
+        const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
+        if (timed) {
+            while (ev_used_ + 2 > ev_pool_.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { last_error = "hipEventCreate failed"; return 0; } ev_pool_.push_back(ev); }
+            (void)hipEventRecord(ev_pool_[ev_used_], stream_);
+        }
+        hipError_t e = launch_fused_pass(stream_, num_cus_, dscene_, cam, ps, max_level_nodes_, sl.d_queue[0], sl.d_queue[1], sl.d_chunk_counts[0], sl.d_chunk_counts[1],
+                                         sl.d_hits, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_counters_);
+        if (e != hipSuccess) { fail(e, "fused pass launch"); return 0; }
+        if (timed) { (void)hipEventRecord(ev_pool_[ev_used_ + 1], stream_); ev_used_ += 2; }
+        ++launches_;
     }
-    current_row = row;
-    if (!end_call((uint64_t)rows.size() * cfg.width)) return 0;
+    current_row = win.next_row;
+    mark_dirty_window(win.first, win.total);
+    counts_pending_ = true; pending_primary_ = (uint64_t)win.total * cfg.width;
     return 50u * cfg.width;
 }
 
@@ -581,25 +693,50 @@ bool Renderer::render(uint32_t spp)
             if (!any) break;
         }
     }
+    for (uint32_t r : owned_rows) ldr_dirty_[r] = 1;
     return end_call((uint64_t)nrows * cfg.width * spp);
 }
 
+// get_tonemapped_pixels, mod.rs:120-128.  The reference maps the whole film on every call although one
+// trace_frame_additive changes 50 rows; here only the rows written since the last read-out are mapped again and
+// copied (into a pinned host mirror of the frame), then the caller gets its own copy of the whole frame.
 bool Renderer::get_tonemapped(uint32_t* out, size_t n)
 {
     if (!bind()) return false;
     const size_t npix = (size_t)cfg.width * cfg.height;
     if (n < npix || !out) { last_error = "output buffer too small"; return false; }
-    HIP_TRY(launch_tonemap(stream_, d_all_rows_, cfg.height, cfg.width, false, d_film_sum_, d_film_n_, d_ldr_));
-    HIP_TRY(hipMemcpyAsync(out, d_ldr_, npix * 4, hipMemcpyDeviceToHost, stream_));
+    if (!h_ldr_) HIP_TRY(hipHostMalloc((void**)&h_ldr_, npix * 4, hipHostMallocDefault));
+    for (uint32_t r = 0; r < cfg.height;) {
+        if (!ldr_dirty_[r]) { ++r; continue; }
+        uint32_t e = r;
+        while (e < cfg.height && ldr_dirty_[e]) ldr_dirty_[e++] = 0;
+        HIP_TRY(launch_tonemap(stream_, nullptr, r, e - r, cfg.width, false, d_film_sum_, d_film_n_, d_ldr_));
+        HIP_TRY(hipMemcpyAsync(h_ldr_ + (size_t)r * cfg.width, d_ldr_ + (size_t)r * cfg.width, (size_t)(e - r) * cfg.width * 4, hipMemcpyDeviceToHost, stream_));
+        r = e;
+    }
     HIP_TRY(hipStreamSynchronize(stream_));
+    std::memcpy(out, h_ldr_, npix * 4);
     return true;
 }
 
-bool Renderer::tonemap_owned_rows_device(uint32_t* device_out, size_t n)
+// Owned rows, packed, into caller-owned DEVICE memory.  caller_stream == null: runs on the handle's stream and
+// returns when done.  Otherwise the kernel is launched on the caller's stream (after everything this handle has
+// queued) and the call returns at once: the write is ordered with whatever the caller does on that stream
+// before and after (its collective, its buffer initialisation).
+bool Renderer::tonemap_owned_rows_device(uint32_t* device_out, size_t n, hipStream_t caller_stream)
 {
     if (!bind()) return false;
     if (n < owned_rows.size() * (size_t)cfg.width || !device_out) { last_error = "output buffer too small"; return false; }
-    HIP_TRY(launch_tonemap(stream_, d_owned_rows_, (uint32_t)owned_rows.size(), cfg.width, true, d_film_sum_, d_film_n_, device_out));
+    if (caller_stream) {
+        HIP_TRY(hipEventRecord(slices_[0].done, stream_));
+        HIP_TRY(hipStreamWaitEvent(caller_stream, slices_[0].done, 0));
+        HIP_TRY(launch_tonemap(caller_stream, d_owned_rows_, 0, (uint32_t)owned_rows.size(), cfg.width, true, d_film_sum_, d_film_n_, device_out));
+        // later work of this handle (film.clear, the next frame) must not overtake the read of the film
+        HIP_TRY(hipEventRecord(ev_tonemap_, caller_stream));
+        HIP_TRY(hipStreamWaitEvent(stream_, ev_tonemap_, 0));
+        return true;
+    }
+    HIP_TRY(launch_tonemap(stream_, d_owned_rows_, 0, (uint32_t)owned_rows.size(), cfg.width, true, d_film_sum_, d_film_n_, device_out));
     HIP_TRY(hipStreamSynchronize(stream_));
     return true;
 }
@@ -621,6 +758,7 @@ bool Renderer::film_clear()
     const size_t npix = (size_t)cfg.width * cfg.height;
     HIP_TRY(hipMemsetAsync(d_film_sum_, 0, npix * 12, stream_));
     HIP_TRY(hipMemsetAsync(d_film_sumsq_, 0, npix * 12, stream_));
+    std::fill(ldr_dirty_.begin(), ldr_dirty_.end(), (uint8_t)1);     // unsampled rows read back white (NaN -> 255)
     HIP_TRY(hipMemsetAsync(d_film_n_, 0, npix * 4, stream_));
     return true;            // stream-ordered: every later call on this handle starts on the same stream
 }
@@ -670,12 +808,48 @@ bool Renderer::debug_numerics(const float* a, const float* b, size_t n, float* q
     return ok;
 }
 
+bool Renderer::debug_slab(const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin)
+{
+    if (!bind()) return false;
+    if (n == 0) return true;
+    if (n > (1u << 24)) { last_error = "too many slab tests in one batch"; return false; }
+    float* d = nullptr; uint8_t* dh = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, n * 4 * 13));
+    bool ok = true;
+    auto chk = [&](hipError_t e, const char* w) { if (ok && e != hipSuccess) ok = fail(e, w); };
+    chk(hipMalloc((void**)&dh, n), "hipMalloc");
+    chk(hipMemcpyAsync(d, inv_rays6, n * 24, hipMemcpyHostToDevice, stream_), "upload rays");
+    chk(hipMemcpyAsync(d + 6 * n, cubes6, n * 24, hipMemcpyHostToDevice, stream_), "upload cubes");
+    if (ok) chk(launch_slab(stream_, d, d + 6 * n, (uint32_t)n, dh, d + 12 * n), "slab kernel");
+    chk(hipMemcpyAsync(hit, dh, n, hipMemcpyDeviceToHost, stream_), "download hit");
+    chk(hipMemcpyAsync(tmin, d + 12 * n, n * 4, hipMemcpyDeviceToHost, stream_), "download tmin");
+    chk(hipStreamSynchronize(stream_), "sync");
+    (void)hipFree(d); if (dh) (void)hipFree(dh);
+    return ok;
+}
+
+// Film::get_pixels / get_estimated_variances computed on the device, downloaded as width*height*3 floats
+bool Renderer::film_stat(bool variances, float* rgb)
+{
+    if (!bind()) return false;
+    const size_t npix = (size_t)cfg.width * cfg.height;
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, npix * 12));
+    bool ok = true;
+    auto chk = [&](hipError_t e, const char* w) { if (ok && e != hipSuccess) ok = fail(e, w); };
+    chk(launch_film_stat(stream_, variances, npix, d_film_sum_, d_film_sumsq_, d_film_n_, d), "film_stat kernel");
+    chk(hipMemcpyAsync(rgb, d, npix * 12, hipMemcpyDeviceToHost, stream_), "download");
+    chk(hipStreamSynchronize(stream_), "sync");
+    (void)hipFree(d);
+    return ok;
+}
+
 bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, float* node_L, size_t nodes)
 {
     if (!bind()) return false;
     if (nodes < nodes_per_sample || pixel >= cfg.width * cfg.height) { last_error = "bad debug_sample arguments"; return false; }
     HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
-    ev_used_ = 0;
+    ev_used_ = 0; counts_pending_ = false;
     if (!run_pass(slices_[0], nullptr, 0, 1, 1, true, pixel, sampleno)) return false;
     HIP_TRY(hipStreamSynchronize(stream_));
     const uint32_t nl = std::max(nlights_, 1u);

@@ -22,10 +22,15 @@ public:
     uint32_t trace_frame_additive();                                   // mod.rs:80-117
     bool render(uint32_t spp);
     bool get_tonemapped(uint32_t* out, size_t n);                       // mod.rs:120-128
-    bool tonemap_owned_rows_device(uint32_t* device_out, size_t n);
+    bool tonemap_owned_rows_device(uint32_t* device_out, size_t n, hipStream_t caller_stream = nullptr);
+    bool last_counts(mi355rt_ray_counts& out);
     bool film_get(float* sum, float* sumsq, uint32_t* n);
+    bool set_seed(uint64_t seed);
+    bool set_flags(uint32_t flags);
     bool film_clear();                                                  // film.rs:37-41
     bool intersect(const float* rays6, size_t n, float* tuv, uint32_t* prim, uint8_t* blocked);
+    bool debug_slab(const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
+    bool film_stat(bool variances, float* rgb);
     bool debug_numerics(const float* a, const float* b, size_t n, float* q, float* r, float* p);
     bool debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, float* node_L, size_t nodes);
 
@@ -72,11 +77,16 @@ private:
     bool ensure_pass_capacity(Slice& sl, size_t nsamples);
     void free_pass_buffers();
     bool assign_slice_rows(uint32_t nslices);
-    bool run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample);
+    bool run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample, uint32_t row_wrap = 0xFFFFFFFFu);
+    void describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t row_wrap, uint32_t npix, size_t nsamples, uint32_t chunk,
+                       bool explicit_sample, uint32_t epixel, uint32_t esample) const;
     bool begin_call();
     bool end_call(uint64_t primary);
+    bool fetch_counts(uint64_t primary, bool timed_call);
+    void mark_dirty_window(uint32_t first, uint32_t total);
     DCamera device_camera() const;
     void collect_cull_boxes();
+    void build_sample_table(std::vector<float>& table4);
     template <class T> bool upload(T*& dptr, const void* src, size_t bytes);
 
     int num_cus_ = 0;
@@ -90,6 +100,11 @@ private:
     float* d_film_sum_ = nullptr; float* d_film_sumsq_ = nullptr; uint32_t* d_film_n_ = nullptr;
     uint32_t* d_owned_rows_ = nullptr; uint32_t* d_all_rows_ = nullptr; uint32_t* d_tmp_rows_ = nullptr;
     uint32_t* d_ldr_ = nullptr;
+    uint32_t* h_ldr_ = nullptr;          // pinned host mirror of d_ldr_ (get_tonemapped_pixels)
+    std::vector<uint8_t> ldr_dirty_;     // per row: film changed since the row was last tone-mapped into d_ldr_ / h_ldr_
+    hipEvent_t ev_tonemap_ = nullptr;
+    bool counts_pending_ = false;        // the last call was an asynchronous 50-row frame: counters not fetched yet
+    uint64_t pending_primary_ = 0;
     DCounters* d_counters_ = nullptr;
     float* d_debug_color_ = nullptr;
     static constexpr uint32_t kMaxSlices = 8;
@@ -99,6 +114,7 @@ private:
     uint32_t chunk_ = 256;               // primary samples per work chunk
     uint32_t max_level_nodes_ = 1;
     uint32_t leaf_threshold_ = 16;
+    bool stash_ = false;                 // trace kernels postpone leaves (speculative traversal), MI355RT_STASH
     bool alloc_failed_ = false;          // the last ensure_pass_capacity failure was an out-of-memory
     uint32_t records_per_sample_ = 1;
     uint32_t nlights_ = 0;

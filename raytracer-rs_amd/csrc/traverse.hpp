@@ -26,6 +26,7 @@ struct RayState {
     uint32_t tri;          // next triangle of the current leaf
     int sp;
     int occ;               // shadow rays: 0 nothing, 1 blocked, 2 unblocked by a hit at t <= 0.01; radiance rays: -1
+    int pend;              // STASH variant of the persistent loop: a postponed leaf (negative leaf code), 0 = none
     bool shadow;
 };
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ void ray_init(RayState& s, f3 o, f3 d, bool shadow, i
     s.selz = __builtin_signbitf(bz) ? 0x01000302u : 0x03020100u;
     s.tlimit = shadow ? 0x1.fffffep-1f : __builtin_inff();     // shadow: t < 1.0
     s.t = __builtin_inff(); s.u = 0.0f; s.v = 0.0f; s.prim = 0xFFFFFFFFu;
-    s.node = root; s.tri = 0u; s.sp = 0; s.occ = shadow ? 0 : -1; s.shadow = shadow;
+    s.node = root; s.tri = 0u; s.sp = 0; s.occ = shadow ? 0 : -1; s.shadow = shadow; s.pend = 0;
 }
 
 // Slab test of one child box of a 32-byte node (bvh.hpp).  Per axis the two half-precision bounds sit
@@ -177,16 +178,32 @@ constexpr int kNodeIdle = (int)0x80000000u, kNodeFin = (int)0x80000001u;
 __device__ __forceinline__ bool lane_at_inner(const RayState& s) { return s.node >= 0; }
 __device__ __forceinline__ bool lane_at_leaf(const RayState& s) { return (uint32_t)s.node > 0x80000001u; }
 
-// pop for the lanes in `want`: next deferred node, or kNodeFin when the stack is empty
+// pop for the lanes in `want`: next deferred node, or kNodeFin when the stack is empty.
+// STASH: when the stack is empty but a leaf is still postponed, that leaf is the next node (the ray is only
+// finished when nothing is deferred AND nothing is postponed).
+template <bool STASH>
 __device__ __forceinline__ int pop_or_finish(RayState& s, bool want, const int* stack, int stride, int trash_row)
 {
     const bool take = want & (s.sp > 0);
     const int popped = stack[(take ? s.sp - 1 : trash_row) * stride];
     s.sp -= take ? 1 : 0;
+    if (STASH) {
+        const bool use_pend = want & !take & (s.pend != 0);
+        const int r = take ? popped : (use_pend ? s.pend : kNodeFin);
+        s.pend = use_pend ? 0 : s.pend;
+        return r;
+    }
     return take ? popped : kNodeFin;
 }
 
-template <bool COUNT>
+// STASH ("speculative traversal", Aila & Laine 2009): a lane whose nearer child is a leaf does not stop there and
+// wait for the triangle section — it POSTPONES the leaf (one per lane) and goes on with the other child or the next
+// deferred node, so the inner-node section keeps more lanes busy and the triangle section finds more work per
+// execution.  The triangles of a postponed leaf are tested later, by the same code; until then the ray's interval is
+// not yet shortened by their hits, so a few more nodes are visited.  Results cannot change: every leaf whose box the
+// ray reaches within its FINAL interval is still tested, and the closest hit / the shadow predicate do not depend on
+// the order of the tests (ties go to the lowest triangle index, not to the first one found).
+template <bool COUNT, bool STASH>
 __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* stack, int stride, int trash_row, uint32_t& n_nodes)
 {
     const bool pred = s.node >= 0;
@@ -203,19 +220,34 @@ __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* s
     const bool sw = tn1 < tn0;                       // child 1 is nearer
     const bool take1 = h1 & (!h0 | sw);
     const int near_c = take1 ? c1i : c0i, far_c = take1 ? c0i : c1i;
-    const bool push = pred & h0 & h1;
+    const bool both = pred & h0 & h1;
     const bool none = pred & !(h0 | h1);
-    stack[(push ? s.sp : trash_row) * stride] = far_c;
-    s.sp += push ? 1 : 0;
-    const int next = pop_or_finish(s, none, stack, stride, trash_row);
-    s.node = pred ? (none ? next : near_c) : s.node;
+    if (STASH) {
+        const bool stash = pred & !none & (near_c < 0) & (s.pend == 0);
+        s.pend = stash ? near_c : s.pend;
+        const bool push = both & !stash;             // postponing the near leaf of two hit children: go straight to the far one
+        const bool pop = none | (stash & !both);
+        stack[(push ? s.sp : trash_row) * stride] = far_c;
+        s.sp += push ? 1 : 0;
+        const int next = pop_or_finish<true>(s, pop, stack, stride, trash_row);
+        s.node = pred ? (pop ? next : (stash ? far_c : near_c)) : s.node;
+    } else {
+        stack[(both ? s.sp : trash_row) * stride] = far_c;
+        s.sp += both ? 1 : 0;
+        const int next = pop_or_finish<false>(s, none, stack, stride, trash_row);
+        s.node = pred ? (none ? next : near_c) : s.node;
+    }
 }
 
-template <bool COUNT>
+__device__ __forceinline__ bool lane_has_leaf_work(const RayState& s) { return lane_at_leaf(s) | (s.pend != 0); }
+
+template <bool COUNT, bool STASH>
 __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const int* stack, int stride, int trash_row, uint32_t& n_tris)
 {
-    const bool pred = lane_at_leaf(s);
-    const uint32_t code = ~(uint32_t)s.node;
+    const bool at_leaf = lane_at_leaf(s);
+    const bool from_pend = STASH ? (!at_leaf & (s.pend != 0)) : false;      // the lane is elsewhere in the tree: test its postponed leaf
+    const bool pred = at_leaf | from_pend;
+    const uint32_t code = ~(uint32_t)(from_pend ? s.pend : s.node);
     if (COUNT) n_tris += pred ? 1u : 0u;
     const uint32_t off = pred ? (code >> 3) * 48u : 0u;              // 48-byte triangles, unsigned 32-bit byte offset
     const char* __restrict__ base = (const char*)sc.tris;
@@ -240,8 +272,15 @@ __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const i
     s.tlimit = better ? t : (sh_far ? 0.01f : s.tlimit);
     s.occ = sh_near ? 2 : (sh_far ? 1 : s.occ);
     const bool last = (code & 7u) == 0u;
-    const int next = pop_or_finish(s, pred & last & !sh_near, stack, stride, trash_row);
-    s.node = pred ? (sh_near ? kNodeFin : (last ? next : s.node - 7)) : s.node;
+    if (STASH) {
+        // a postponed leaf: step it, drop it after its last triangle; the lane's node is untouched unless the ray ends here
+        s.pend = from_pend ? ((last | sh_near) ? 0 : s.pend - 7) : (sh_near ? 0 : s.pend);
+        const int next = pop_or_finish<true>(s, at_leaf & last & !sh_near, stack, stride, trash_row);
+        s.node = sh_near ? kNodeFin : (at_leaf ? (last ? next : s.node - 7) : s.node);
+    } else {
+        const int next = pop_or_finish<false>(s, pred & last & !sh_near, stack, stride, trash_row);
+        s.node = pred ? (sh_near ? kNodeFin : (last ? next : s.node - 7)) : s.node;
+    }
 }
 
 // ---- reference-exact intersector (MI355RT_FLAG_OCTREE_SEMANTICS) ---------------------------------------
@@ -250,6 +289,21 @@ __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const i
 // tmin with a STABLE sort, visited front to back, FIRST leaf that yields a hit wins; a leaf yields its
 // closest triangle only if the hit point lies inside the leaf cube (inclusive).  The root cube is never
 // slab-tested.  A slow path by design (<= 70 triangles per leaf): it exists for parity, not for speed.
+// intersect_cube_inverse_ray, OCT:348-372: slab test with the precomputed inverse direction; returns the entry
+// distance tmin (negative when the origin is inside).  fminf/fmaxf ignore a NaN operand like Rust's f32::min/max,
+// so 0 * inf lanes behave as in the reference.
+__device__ __forceinline__ bool cube_slab(f3 cmin, f3 cmax, f3 o, f3 inv, float& tmin_out)
+{
+    const float tx1 = (cmin.x - o.x) * inv.x, tx2 = (cmax.x - o.x) * inv.x;
+    float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
+    const float ty1 = (cmin.y - o.y) * inv.y, ty2 = (cmax.y - o.y) * inv.y;
+    tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+    const float tz1 = (cmin.z - o.z) * inv.z, tz2 = (cmax.z - o.z) * inv.z;
+    tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+    tmin_out = tmin;
+    return tmax >= tmin && tmax > 0.0f;
+}
+
 __device__ inline void octree_intersect(const DScene& sc, f3 o, f3 d, float& out_t, float& out_u, float& out_v, uint32_t& out_prim)
 {
     const float4* __restrict__ nodes = (const float4*)sc.oct_nodes;
@@ -296,14 +350,8 @@ __device__ inline void octree_intersect(const DScene& sc, f3 o, f3 d, float& out
         for (int i = 0; i < 8; ++i) {
             const int c = first_child + i;
             const float4 c0 = nodes[3 * c], c1 = nodes[3 * c + 1];
-            // intersect_cube_inverse_ray, OCT:348-372 (fminf/fmaxf ignore a NaN operand like f32::min/max)
-            const float tx1 = (c0.x - o.x) * inv.x, tx2 = (c1.x - o.x) * inv.x;
-            float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
-            const float ty1 = (c0.y - o.y) * inv.y, ty2 = (c1.y - o.y) * inv.y;
-            tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
-            const float tz1 = (c0.z - o.z) * inv.z, tz2 = (c1.z - o.z) * inv.z;
-            tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
-            if (tmax >= tmin && tmax > 0.0f) {
+            float tmin;
+            if (cube_slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), o, inv, tmin)) {
                 // stable insertion by tmin ascending (OCT:183); a NaN distance compares as "not less"
                 int j = n - 1;
                 while (j >= 0 && tmin < dist[j]) { idx[j + 1] = idx[j]; dist[j + 1] = dist[j]; --j; }
