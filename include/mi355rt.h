@@ -42,6 +42,9 @@ extern "C" {
  * whose closest triangle's hit point lies inside the leaf cube wins).  A slow parity path; without it
  * the BVH returns the true closest hit (no_acceleration_intersector.rs semantics). */
 #define MI355RT_FLAG_OCTREE_SEMANTICS 8u
+/* CREATE-time flag, testing only: the members of a device group (config.device_count > 1) all use config.device
+ * instead of consecutive devices, so that the group's decomposition and gather run on a single-GPU machine. */
+#define MI355RT_FLAG_GROUP_SHARES_DEVICE 16u
 
 typedef struct mi355rt_handle mi355rt_handle;
 
@@ -96,6 +99,12 @@ typedef struct mi355rt_config {
      * stripe_world <= 1 renders every row. */
     uint32_t stripe_rows, stripe_rank, stripe_world;
     uint32_t samples_per_pass;       /* samples per pixel traced per wavefront pass (0 = auto) */
+    /* Device group: the handle drives `device_count` HIP devices of THIS process (device, device + 1, ...).  Rows
+     * are dealt to them in stripes of stripe_rows; every entry point works on the group as on one device (the
+     * reference's callers see one RayTracer, main.rs:183-216); mi355rt_get_tonemapped_pixels gathers the packed
+     * stripes on the first device with hipMemcpyPeerAsync over xGMI.  0 or 1: one device.  Not combinable with
+     * stripe_world > 1 (that is the one-process-per-GPU decomposition, gathered with mi355rt_comm_*). */
+    uint32_t device_count;
 } mi355rt_config;
 
 /* Ray counters of one mi355rt_render / mi355rt_trace_frame_additive call. */
@@ -217,6 +226,25 @@ int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8]);
 /* reference-exact mode only: out[0] octree nodes, [1] inner, [2] leaves, [3] empty leaves, [4] depth,
  * [5] triangle references (the quantities of SURVEY.md 6.2) */
 int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8]);
+/* devices of the handle's group (1 for an ordinary handle) */
+uint32_t mi355rt_device_count(const mi355rt_handle* h);
+/* wait until everything queued on the handle (50-row frames, gathers) has finished on its device(s) */
+int mi355rt_synchronize(mi355rt_handle* h);
+
+/* ---- one process per GPU: the framebuffer gather over RCCL / xGMI (no reference counterpart: the reference is
+ * one process on one CPU).  Every process creates its handle with stripe_rank / stripe_world = its rank / the
+ * number of processes.  Rank 0 obtains a 128-byte id (ncclUniqueId) with mi355rt_comm_unique_id and hands it to the
+ * others by whatever means the host application has; then ALL ranks call mi355rt_comm_init (collective).
+ * mi355rt_comm_gather_frame (collective) maps every rank's rows to packed u32 and moves them to `root` with grouped
+ * ncclSend / ncclRecv on the handle's stream; the root places them into its frame.  host_out (root only, may be
+ * NULL): width*height u32 copied out after a synchronisation; with NULL the call only queues the work
+ * (mi355rt_synchronize waits for it).  librccl.so is loaded on first use. */
+#define MI355RT_COMM_ID_BYTES 128
+int mi355rt_comm_unique_id(uint8_t* id128);
+int mi355rt_comm_init(mi355rt_handle* h, const uint8_t* id128);
+int mi355rt_comm_gather_frame(mi355rt_handle* h, uint32_t root, uint32_t* host_out, size_t n);
+int mi355rt_comm_destroy(mi355rt_handle* h);
+
 uint32_t mi355rt_width(const mi355rt_handle* h);
 uint32_t mi355rt_height(const mi355rt_handle* h);
 uint32_t mi355rt_triangle_count(const mi355rt_handle* h);

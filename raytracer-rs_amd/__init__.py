@@ -29,6 +29,7 @@ FLAG_FIX_ROW_INDEX = 1
 FLAG_COUNT_STEPS = 2
 FLAG_TIME_KERNELS = 4
 FLAG_OCTREE_SEMANTICS = 8
+FLAG_GROUP_SHARES_DEVICE = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
@@ -63,7 +64,7 @@ class Config(C.Structure):
         ("recursions", C.c_uint32), ("spread", C.c_uint32), ("flags", C.c_uint32),
         ("seed", C.c_uint64), ("device", C.c_int32),
         ("stripe_rows", C.c_uint32), ("stripe_rank", C.c_uint32), ("stripe_world", C.c_uint32),
-        ("samples_per_pass", C.c_uint32),
+        ("samples_per_pass", C.c_uint32), ("device_count", C.c_uint32),
     ]
 
 
@@ -125,6 +126,12 @@ ABI = [
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
     ("mi355rt_octree_stats", C.c_int, [_H, _U]),
+    ("mi355rt_device_count", C.c_uint32, [_H]),
+    ("mi355rt_synchronize", C.c_int, [_H]),
+    ("mi355rt_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
+    ("mi355rt_comm_init", C.c_int, [_H, C.POINTER(C.c_uint8)]),
+    ("mi355rt_comm_gather_frame", C.c_int, [_H, C.c_uint32, _U, C.c_size_t]),
+    ("mi355rt_comm_destroy", C.c_int, [_H]),
     ("mi355rt_width", C.c_uint32, [_H]),
     ("mi355rt_height", C.c_uint32, [_H]),
     ("mi355rt_triangle_count", C.c_uint32, [_H]),
@@ -285,6 +292,29 @@ class RayTracer:
     def get_slices(self):
         return int(lib().mi355rt_get_slices(self._h))
 
+    def synchronize(self):
+        self._check(lib().mi355rt_synchronize(self._h))
+
+    @property
+    def device_count(self):
+        return int(lib().mi355rt_device_count(self._h))
+
+    # --- one process per GPU: RCCL gather inside the library (include/mi355rt.h, mi355rt_comm_*)
+    def comm_init(self, id128):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        self._check(lib().mi355rt_comm_init(self._h, buf))
+
+    def comm_gather_frame(self, root=0, out=None):
+        """collective; `out` (uint32[width*height], root only) receives the frame, None only queues the transfers"""
+        if out is None:
+            self._check(lib().mi355rt_comm_gather_frame(self._h, root, None, 0))
+        else:
+            self._check(lib().mi355rt_comm_gather_frame(self._h, root, _up(out), out.size))
+        return out
+
+    def comm_destroy(self):
+        self._check(lib().mi355rt_comm_destroy(self._h))
+
     def owned_rows(self):
         n = lib().mi355rt_owned_rows(self._h)
         rows = np.zeros(n, np.uint32)
@@ -424,6 +454,14 @@ def create_raytracer_from_arrays(scene, triangles_per_leaf, width, height, **cfg
     h = C.c_void_p()
     code = lib().mi355rt_create(C.byref(sd), C.byref(cfg), C.byref(h))
     return _finish(code, h, keep)
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it, the host application hands it to the other ranks)"""
+    buf = (C.c_uint8 * 128)()
+    if lib().mi355rt_comm_unique_id(buf) != 0:
+        raise RuntimeError((lib().mi355rt_last_error(None) or b"").decode() or "mi355rt_comm_unique_id failed")
+    return bytes(buf)
 
 
 class Stats:

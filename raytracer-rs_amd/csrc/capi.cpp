@@ -3,12 +3,19 @@
 #include <memory>
 #include <string>
 #include "../../include/mi355rt.h"
+#include "group.hpp"
 #include "renderer.hpp"
 
 using namespace mi355rt;
 
+namespace mi355rt { bool comm_unique_id(uint8_t* id128, std::string& err); }
+
+// A handle is a device group (csrc/group.hpp): one renderer per HIP device of this process, usually exactly one.
+// `r` is the primary renderer (device 0 of the group): entry points that do not depend on the decomposition use it.
 struct mi355rt_handle {
-    std::unique_ptr<Renderer> r;
+    std::unique_ptr<DeviceGroup> g;
+    Renderer* r;
+    std::string error;      // error text of group-level failures
 };
 
 namespace {
@@ -18,9 +25,10 @@ int finish_create(const SceneData& scene, const mi355rt_config* cfg, mi355rt_han
 {
     int code = MI355RT_E_INVALID;
     std::string err;
-    std::unique_ptr<Renderer> r = Renderer::create(scene, *cfg, err, code);
-    if (!r) { g_create_error = err; return code; }
-    *out = new mi355rt_handle{ std::move(r) };
+    std::unique_ptr<DeviceGroup> g = DeviceGroup::create(scene, *cfg, err, code);
+    if (!g) { g_create_error = err; return code; }
+    Renderer* r = g->primary();
+    *out = new mi355rt_handle{ std::move(g), r, std::string() };
     return MI355RT_OK;
 }
 int bad(const char* msg) { g_create_error = msg; return MI355RT_E_INVALID; }
@@ -37,6 +45,7 @@ void mi355rt_default_config(mi355rt_config* cfg)
     cfg->recursions = 2; cfg->spread = 1;                         // mod.rs:81-82
     cfg->seed = 1; cfg->device = 0;
     cfg->stripe_rows = 8; cfg->stripe_rank = 0; cfg->stripe_world = 1;
+    cfg->device_count = 1;
 }
 
 int mi355rt_create(const mi355rt_scene_desc* s, const mi355rt_config* cfg, mi355rt_handle** out)
@@ -101,33 +110,34 @@ int mi355rt_create_from_scene_file(const char* path, const mi355rt_config* cfg, 
 
 void mi355rt_destroy(mi355rt_handle* h) { delete h; }
 
-const char* mi355rt_last_error(const mi355rt_handle* h) { return h ? h->r->last_error.c_str() : g_create_error.c_str(); }
+const char* mi355rt_last_error(const mi355rt_handle* h) { return h ? h->g->last_error().c_str() : g_create_error.c_str(); }
 
-uint32_t mi355rt_trace_frame_additive(mi355rt_handle* h) { return h ? h->r->trace_frame_additive() : 0u; }
+uint32_t mi355rt_trace_frame_additive(mi355rt_handle* h) { return h ? h->g->trace_frame_additive() : 0u; }
 
 int mi355rt_render(mi355rt_handle* h, uint32_t spp, mi355rt_ray_counts* counts)
 {
     if (!h) return MI355RT_E_INVALID;
-    bool ok = h->r->render(spp);
-    if (counts) *counts = h->r->counts;
+    bool ok = h->g->render(spp);
+    if (counts) { if (h->g->size() == 1) *counts = h->r->counts; else (void)h->g->last_counts(*counts); }
     return ok ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_last_counts(mi355rt_handle* h, mi355rt_ray_counts* counts)
 {
     if (!h || !counts) return MI355RT_E_INVALID;
-    return h->r->last_counts(*counts) ? MI355RT_OK : MI355RT_E_HIP;
+    return h->g->last_counts(*counts) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_get_tonemapped_pixels(mi355rt_handle* h, uint32_t* out, size_t n)
 {
     if (!h) return MI355RT_E_INVALID;
-    return h->r->get_tonemapped(out, n) ? MI355RT_OK : MI355RT_E_HIP;
+    return h->g->get_tonemapped(out, n) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_tonemap_owned_rows_device(mi355rt_handle* h, uint32_t* device_out, size_t n)
 {
     if (!h) return MI355RT_E_INVALID;
+    if (h->g->size() > 1) { h->r->last_error = "not available on a device group: use mi355rt_get_tonemapped_pixels"; return MI355RT_E_INVALID; }
     return h->r->tonemap_owned_rows_device(device_out, n) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
@@ -135,14 +145,17 @@ int mi355rt_tonemap_owned_rows_device_on_stream(mi355rt_handle* h, uint32_t* dev
 {
     if (!h) return MI355RT_E_INVALID;
     if (!hip_stream) { h->r->last_error = "null stream: use mi355rt_tonemap_owned_rows_device"; return MI355RT_E_INVALID; }
+    if (h->g->size() > 1) { h->r->last_error = "not available on a device group: use mi355rt_get_tonemapped_pixels"; return MI355RT_E_INVALID; }
     return h->r->tonemap_owned_rows_device(device_out, n, (hipStream_t)hip_stream) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
-uint32_t mi355rt_owned_rows(const mi355rt_handle* h) { return h ? (uint32_t)h->r->owned_rows.size() : 0u; }
+// a device group owns every row of the frame (its devices share them out among themselves)
+uint32_t mi355rt_owned_rows(const mi355rt_handle* h) { return !h ? 0u : h->g->size() > 1 ? h->r->cfg.height : (uint32_t)h->r->owned_rows.size(); }
 
 int mi355rt_owned_row_list(const mi355rt_handle* h, uint32_t* rows, size_t n)
 {
-    if (!h || !rows || n < h->r->owned_rows.size()) return MI355RT_E_INVALID;
+    if (!h || !rows || n < mi355rt_owned_rows(h)) return MI355RT_E_INVALID;
+    if (h->g->size() > 1) { for (uint32_t r = 0; r < h->r->cfg.height; ++r) rows[r] = r; return MI355RT_OK; }
     std::memcpy(rows, h->r->owned_rows.data(), h->r->owned_rows.size() * 4);
     return MI355RT_OK;
 }
@@ -150,43 +163,43 @@ int mi355rt_owned_row_list(const mi355rt_handle* h, uint32_t* rows, size_t n)
 int mi355rt_film_get(mi355rt_handle* h, float* sum_rgb, float* sumsq_rgb, uint32_t* n)
 {
     if (!h) return MI355RT_E_INVALID;
-    return h->r->film_get(sum_rgb, sumsq_rgb, n) ? MI355RT_OK : MI355RT_E_HIP;
+    return h->g->film_get(sum_rgb, sumsq_rgb, n) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_film_clear(mi355rt_handle* h)
 {
     if (!h) return MI355RT_E_INVALID;
-    return h->r->film_clear() ? MI355RT_OK : MI355RT_E_HIP;
+    return h->g->film_clear() ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_film_get_pixels(mi355rt_handle* h, float* rgb)
 {
     if (!h || !rgb) return MI355RT_E_INVALID;
-    return h->r->film_stat(false, rgb) ? MI355RT_OK : MI355RT_E_HIP;
+    return h->g->film_stat(false, rgb) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_film_get_estimated_variances(mi355rt_handle* h, float* rgb)
 {
     if (!h || !rgb) return MI355RT_E_INVALID;
-    return h->r->film_stat(true, rgb) ? MI355RT_OK : MI355RT_E_HIP;
+    return h->g->film_stat(true, rgb) ? MI355RT_OK : MI355RT_E_HIP;
 }
 
 int mi355rt_camera_move_rel(mi355rt_handle* h, float x, float y, float z)
 {
     if (!h) return MI355RT_E_INVALID;
-    h->r->camera.move_rel(x, y, z);
+    h->g->camera_move_rel(x, y, z);
     return MI355RT_OK;
 }
 int mi355rt_camera_add_x_angle(mi355rt_handle* h, float radians)
 {
     if (!h) return MI355RT_E_INVALID;
-    h->r->camera.add_x_angle(radians);
+    h->g->camera_add_x_angle(radians);
     return MI355RT_OK;
 }
 int mi355rt_camera_add_y_angle(mi355rt_handle* h, float radians)
 {
     if (!h) return MI355RT_E_INVALID;
-    h->r->camera.add_y_angle(radians);
+    h->g->camera_add_y_angle(radians);
     return MI355RT_OK;
 }
 int mi355rt_camera_get(const mi355rt_handle* h, float rot16[16], float orient16[16], float max_xy[2])
@@ -208,18 +221,18 @@ int mi355rt_camera_get_ray(const mi355rt_handle* h, uint32_t u, uint32_t v, floa
 int mi355rt_set_seed(mi355rt_handle* h, uint64_t seed)
 {
     if (!h) return MI355RT_E_INVALID;
-    return h->r->set_seed(seed) ? MI355RT_OK : MI355RT_E_HIP;
+    return h->g->set_seed(seed) ? MI355RT_OK : MI355RT_E_HIP;
 }
 int mi355rt_set_flags(mi355rt_handle* h, uint32_t flags)
 {
     if (!h) return MI355RT_E_INVALID;
-    return h->r->set_flags(flags) ? MI355RT_OK : MI355RT_E_INVALID;
+    return h->g->set_flags(flags) ? MI355RT_OK : MI355RT_E_INVALID;
 }
 
 int mi355rt_set_slices(mi355rt_handle* h, uint32_t slices)
 {
     if (!h || slices < 1 || slices > 8) return MI355RT_E_INVALID;
-    h->r->slices = slices; h->r->slices_explicit = true;
+    h->g->set_slices(slices);
     return MI355RT_OK;
 }
 uint32_t mi355rt_get_slices(const mi355rt_handle* h) { return h ? h->r->slices : 0; }
@@ -274,6 +287,39 @@ int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8])
     std::memcpy(out, h->r->oct_stats_, sizeof h->r->oct_stats_);
     return MI355RT_OK;
 }
+uint32_t mi355rt_device_count(const mi355rt_handle* h) { return h ? (uint32_t)h->g->size() : 0u; }
+
+int mi355rt_synchronize(mi355rt_handle* h)
+{
+    if (!h) return MI355RT_E_INVALID;
+    return h->g->synchronize() ? MI355RT_OK : MI355RT_E_HIP;
+}
+
+int mi355rt_comm_unique_id(uint8_t* id128)
+{
+    if (!id128) return bad("null argument");
+    std::string err;
+    if (!comm_unique_id(id128, err)) { g_create_error = err; return MI355RT_E_HIP; }
+    return MI355RT_OK;
+}
+int mi355rt_comm_init(mi355rt_handle* h, const uint8_t* id128)
+{
+    if (!h || !id128) return MI355RT_E_INVALID;
+    if (h->g->size() > 1) { h->r->last_error = "a device group gathers inside the process; RCCL communicators are for one-device handles"; return MI355RT_E_INVALID; }
+    return h->r->comm_init(id128) ? MI355RT_OK : MI355RT_E_HIP;
+}
+int mi355rt_comm_gather_frame(mi355rt_handle* h, uint32_t root, uint32_t* host_out, size_t n)
+{
+    if (!h) return MI355RT_E_INVALID;
+    return h->r->comm_gather(root, host_out, n) ? MI355RT_OK : MI355RT_E_HIP;
+}
+int mi355rt_comm_destroy(mi355rt_handle* h)
+{
+    if (!h) return MI355RT_E_INVALID;
+    h->r->comm_destroy();
+    return MI355RT_OK;
+}
+
 uint32_t mi355rt_width(const mi355rt_handle* h) { return h ? h->r->cfg.width : 0u; }
 uint32_t mi355rt_height(const mi355rt_handle* h) { return h ? h->r->cfg.height : 0u; }
 uint32_t mi355rt_triangle_count(const mi355rt_handle* h) { return h ? h->r->ntri : 0u; }

@@ -928,6 +928,28 @@ hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t row
     return hipGetLastError();
 }
 
+// ---- multi-GPU gather, last step on the root: packed stripes of every rank -> the full frame -----------------
+// gathered = world slots of slot_rows * width u32; slot r holds rank r's owned rows in ascending order (rows are dealt
+// in stripes of stripe_rows, stripe s to rank s % world: Renderer::init).  One thread per pixel of the frame.
+__global__ __launch_bounds__(256) void place_stripes_kernel(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
+                                                           uint32_t width, uint32_t height, uint32_t stripe_rows, uint32_t world, uint32_t slot_rows)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)width * height) return;
+    const uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (size_t)y * width);
+    const uint32_t stripe = y / stripe_rows, rank = stripe % world;
+    const uint32_t local_row = (stripe / world) * stripe_rows + (y - stripe * stripe_rows);
+    frame[i] = gathered[((size_t)rank * slot_rows + local_row) * width + x];
+}
+hipError_t launch_place_stripes(hipStream_t stream, const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height,
+                                uint32_t stripe_rows, uint32_t world, uint32_t slot_rows)
+{
+    const size_t n = (size_t)width * height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(place_stripes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gathered, frame, width, height, stripe_rows, world, slot_rows);
+    return hipGetLastError();
+}
+
 // rows of LDS the fused kernel needs: the traversal stack (+ trash row) or the wave's hit list, whichever is larger
 uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes)
 {

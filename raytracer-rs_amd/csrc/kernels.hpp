@@ -26,6 +26,9 @@ hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t row
                           const float* film_sum, const uint32_t* film_n, uint32_t* out);
 hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack_depth, const float* rays6, uint32_t n, bool shadow_mode,
                             float* tuv, uint32_t* prim, uint8_t* blocked);
+// multi-GPU gather on the root: world slots of slot_rows packed rows each -> full frame
+hipError_t launch_place_stripes(hipStream_t stream, const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height,
+                                uint32_t stripe_rows, uint32_t world, uint32_t slot_rows);
 hipError_t launch_slab(hipStream_t stream, const float* inv_rays6, const float* cubes6, uint32_t n, uint8_t* hit, float* tmin);
 hipError_t launch_film_stat(hipStream_t stream, bool variances, size_t npix, const float* film_sum, const float* film_sumsq, const uint32_t* film_n, float* out);
 hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, uint32_t n, float* q, float* r, float* p);

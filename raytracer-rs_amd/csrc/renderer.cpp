@@ -213,7 +213,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_film_sum_, nullptr, npix * 12) || !upload(d_film_sumsq_, nullptr, npix * 12) || !upload(d_film_n_, nullptr, npix * 4)) return bail();
     if (!upload(d_ldr_, nullptr, npix * 4)) return bail();
     ldr_dirty_.assign(cfg.height, (uint8_t)1);
-    if (hipEventCreateWithFlags(&ev_tonemap_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
+    if (hipEventCreateWithFlags(&ev_tonemap_, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_gather_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
     std::vector<uint32_t> all(cfg.height);
     for (uint32_t r = 0; r < cfg.height; ++r) {
         all[r] = r;
@@ -260,7 +260,10 @@ Renderer::~Renderer()
     }
     for (void* p : allocs_) (void)hipFree(p);
     if (h_ldr_) (void)hipHostFree(h_ldr_);
+    comm_destroy();
+    if (d_gather_) (void)hipFree(d_gather_);
     if (ev_tonemap_) (void)hipEventDestroy(ev_tonemap_);
+    if (ev_gather_) (void)hipEventDestroy(ev_gather_);
     free_pass_buffers();
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
@@ -738,6 +741,56 @@ bool Renderer::tonemap_owned_rows_device(uint32_t* device_out, size_t n, hipStre
     }
     HIP_TRY(launch_tonemap(stream_, d_owned_rows_, 0, (uint32_t)owned_rows.size(), cfg.width, true, d_film_sum_, d_film_n_, device_out));
     HIP_TRY(hipStreamSynchronize(stream_));
+    return true;
+}
+
+bool Renderer::synchronize()
+{
+    if (!bind()) return false;
+    for (Slice& o : slices_) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
+    return true;
+}
+
+// ---- multi-GPU gather ------------------------------------------------------------------------------------------
+uint32_t Renderer::slot_rows() const
+{
+    const uint32_t stripes = (cfg.height + cfg.stripe_rows - 1) / cfg.stripe_rows;
+    return ((stripes + cfg.stripe_world - 1) / cfg.stripe_world) * cfg.stripe_rows;
+}
+uint32_t Renderer::rows_of_rank(uint32_t rank) const
+{
+    uint32_t n = 0;
+    for (uint32_t s = rank; (uint64_t)s * cfg.stripe_rows < cfg.height; s += cfg.stripe_world) n += std::min(cfg.stripe_rows, cfg.height - s * cfg.stripe_rows);
+    return n;
+}
+bool Renderer::gather_prepare(bool root)
+{
+    if (!bind()) return false;
+    if (d_gather_ && gather_is_root_ == root) return true;
+    if (d_gather_) { HIP_TRY(hipStreamSynchronize(stream_)); (void)hipFree(d_gather_); d_gather_ = nullptr; }
+    const size_t slot = (size_t)slot_rows() * cfg.width * 4;
+    HIP_TRY(hipMalloc((void**)&d_gather_, slot * (root ? cfg.stripe_world : 1)));
+    gather_is_root_ = root;
+    return true;
+}
+bool Renderer::tonemap_to_gather_slot()
+{
+    if (!bind()) return false;
+    HIP_TRY(launch_tonemap(stream_, d_owned_rows_, 0, (uint32_t)owned_rows.size(), cfg.width, true, d_film_sum_, d_film_n_, gather_slot(cfg.stripe_rank)));
+    return true;
+}
+bool Renderer::finish_gather(uint32_t* host_out, size_t n)
+{
+    if (!bind()) return false;
+    const size_t npix = (size_t)cfg.width * cfg.height;
+    if (host_out && n < npix) { last_error = "output buffer too small"; return false; }
+    HIP_TRY(launch_place_stripes(stream_, d_gather_, d_ldr_, cfg.width, cfg.height, cfg.stripe_rows, cfg.stripe_world, slot_rows()));
+    if (host_out) {
+        if (!h_ldr_) HIP_TRY(hipHostMalloc((void**)&h_ldr_, npix * 4, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(h_ldr_, d_ldr_, npix * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::memcpy(host_out, h_ldr_, npix * 4);
+    }
     return true;
 }
 

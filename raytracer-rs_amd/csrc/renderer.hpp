@@ -29,6 +29,20 @@ public:
     bool set_flags(uint32_t flags);
     bool film_clear();                                                  // film.rs:37-41
     bool intersect(const float* rays6, size_t n, float* tuv, uint32_t* prim, uint8_t* blocked);
+    bool synchronize();                                                 // wait for everything queued on this handle
+    // ---- multi-GPU gather of the packed u32 stripes into the root's frame.  Two transports end in the
+    // same place: the in-process device group (hipMemcpyPeerAsync, csrc/group.cpp) and RCCL between processes (comm_*).
+    uint32_t slot_rows() const;                                         // rows of one rank's slot: ceil(stripes / world) * stripe_rows
+    uint32_t rows_of_rank(uint32_t rank) const;
+    bool gather_prepare(bool root);                                     // root: world slots, others: their own slot
+    uint32_t* gather_slot(uint32_t rank) { return d_gather_ ? d_gather_ + (gather_is_root_ ? (size_t)rank : 0) * slot_rows() * cfg.width : nullptr; }
+    bool tonemap_to_gather_slot();                                      // own rows, packed, into the own slot (on the handle's stream)
+    bool finish_gather(uint32_t* host_out, size_t n);                   // root: slots -> frame (+ copy to the host when host_out != null)
+    hipStream_t stream() const { return stream_; }
+    hipEvent_t gather_event() const { return ev_gather_; }
+    bool comm_init(const uint8_t* id128);                               // RCCL communicator over the stripe ranks (collective)
+    bool comm_gather(uint32_t root, uint32_t* host_out, size_t n);      // collective: grouped ncclSend / ncclRecv to the root, then finish_gather there
+    void comm_destroy();
     bool debug_slab(const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
     bool film_stat(bool variances, float* rgb);
     bool debug_numerics(const float* a, const float* b, size_t n, float* q, float* r, float* p);
@@ -102,7 +116,10 @@ private:
     uint32_t* d_ldr_ = nullptr;
     uint32_t* h_ldr_ = nullptr;          // pinned host mirror of d_ldr_ (get_tonemapped_pixels)
     std::vector<uint8_t> ldr_dirty_;     // per row: film changed since the row was last tone-mapped into d_ldr_ / h_ldr_
-    hipEvent_t ev_tonemap_ = nullptr;
+    hipEvent_t ev_tonemap_ = nullptr, ev_gather_ = nullptr;
+    uint32_t* d_gather_ = nullptr;       // gather slots (see gather_prepare)
+    bool gather_is_root_ = false;
+    void* comm_ = nullptr;               // ncclComm_t
     bool counts_pending_ = false;        // the last call was an asynchronous 50-row frame: counters not fetched yet
     uint64_t pending_primary_ = 0;
     DCounters* d_counters_ = nullptr;

@@ -35,6 +35,7 @@ pub const DEFAULT_TRIANGLES_PER_LEAF: usize = 70;
 #[repr(C)] struct mi355rt_config {
     width: u32, height: u32, triangles_per_leaf: u32, recursions: u32, spread: u32, flags: u32,
     seed: u64, device: i32, stripe_rows: u32, stripe_rank: u32, stripe_world: u32, samples_per_pass: u32,
+    device_count: u32,      // > 1: the handle drives that many GPUs of this process (rows dealt in stripes, gathered on the first)
 }
 extern "C" {
     fn mi355rt_default_config(cfg: *mut mi355rt_config);

@@ -44,3 +44,34 @@ class FrameGather:
         for r in range(self.world):
             f[self.rows[r]] = g[r, : self.rows[r].numel()]
         return self.frame
+
+
+class NativeGather:
+    """The gather INSIDE libmi355rt.so (include/mi355rt.h, mi355rt_comm_*): grouped ncclSend / ncclRecv of the packed u32
+    stripes to rank 0 on the handle's own stream, placement kernel on the root.  torch.distributed is used ONLY to hand
+    the 128-byte RCCL id from rank 0 to the other ranks and to agree that every rank got its communicator."""
+
+    def __init__(self, pkg, rt, dist, rank, world):
+        self.rt = rt
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        ok = 1
+        try:
+            rt.comm_init(bytes(idt.cpu().numpy().tobytes()))
+        except Exception as e:          # noqa: BLE001 — the failure is agreed on below, then raised on every rank
+            ok, self.error = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            if ok:
+                rt.comm_destroy()
+            raise RuntimeError("mi355rt_comm_init failed on some rank" + (": " + self.error if not ok else ""))
+
+    def gather(self):
+        self.rt.comm_gather_frame(0, None)          # queued on the handle's stream; rt.synchronize() waits for it
+
+    def close(self):
+        self.rt.synchronize()
+        self.rt.comm_destroy()

@@ -77,3 +77,27 @@ def test_frame_gather_over_gloo_ranks(world, h, w, sr):
     for p in procs:
         p.join(60)
     assert res == [(r, True) for r in range(world)]
+
+
+def test_gather_slot_arithmetic_matches_the_placement_kernel(pkg):
+    """place_stripes_kernel (csrc/kernels.hip) and Renderer::slot_rows / rows_of_rank (csrc/renderer.cpp), restated:
+    rank r's packed rows land in slot r; pixel (y, x) of the frame comes from slot (y / stripe) % world at local row
+    (y / stripe / world) * stripe + y % stripe.  Checked against stripes.owned_rows for 1..8 ranks and ragged heights."""
+    import importlib
+    stripes = importlib.import_module("raytracer_rs_amd.stripes")
+    for height in (1, 7, 8, 50, 131, 1080, 2160):
+        for stripe_rows in (1, 4, 8):
+            for world in (1, 2, 3, 8):
+                nstripes = (height + stripe_rows - 1) // stripe_rows
+                slot_rows = ((nstripes + world - 1) // world) * stripe_rows
+                assert slot_rows == stripes.max_owned_rows(height, stripe_rows, world)
+                seen = set()
+                for r in range(world):
+                    rows = stripes.owned_rows(height, stripe_rows, r, world)
+                    n = sum(min(stripe_rows, height - s * stripe_rows) for s in range(r, nstripes, world))
+                    assert n == len(rows) <= slot_rows
+                    for local, y in enumerate(rows):
+                        s_ = y // stripe_rows
+                        assert s_ % world == r and (s_ // world) * stripe_rows + (y - s_ * stripe_rows) == local
+                        seen.add(y)
+                assert seen == set(range(height))
