@@ -37,11 +37,18 @@ extern "C" {
 #define MI355RT_FLAG_FIX_ROW_INDEX  1u  /* v = idx / width instead of the reference's idx / height (mod.rs:93-96) */
 #define MI355RT_FLAG_COUNT_STEPS    2u  /* instrumented traversal: count BVH nodes visited / triangles tested */
 #define MI355RT_FLAG_TIME_KERNELS   4u  /* bracket every trace-kernel launch with HIP events */
-/* CREATE-time flag: intersect with the reference's own octree (built with config.triangles_per_leaf),
- * traversal bug for bug (oct_tree_intersector.rs:148-206: sorted front-to-back children, first leaf
- * whose closest triangle's hit point lies inside the leaf cube wins).  A slow parity path; without it
- * the BVH returns the true closest hit (no_acceleration_intersector.rs semantics). */
+/* Intersector semantics — CREATE-time flags.
+ *   default (neither flag): the reference's DEFAULT intersector, OctTreeIntersector (lib.rs:29-44 wires it): sorted
+ *     front-to-back children, first leaf whose closest triangle's hit point lies inside the leaf cube wins
+ *     (oct_tree_intersector.rs:148-206).  Served by the BVH (true closest hit) plus the octree CONFIRM step, which derives
+ *     the octree's answer from the true closest hit exactly (csrc/traverse.hpp, confirm_walk); the octree is built with
+ *     config.triangles_per_leaf.
+ *   MI355RT_FLAG_OCTREE_SEMANTICS: the same semantics by walking the reference's octree directly, bug for bug — slow;
+ *     kept as the independent cross-check of the confirm step.
+ *   MI355RT_FLAG_TRUE_CLOSEST_HIT: the true closest hit, i.e. the reference's NoAccelerationIntersector
+ *     (no_acceleration_intersector.rs:13-41); no octree is built, triangles_per_leaf is ignored. */
 #define MI355RT_FLAG_OCTREE_SEMANTICS 8u
+#define MI355RT_FLAG_TRUE_CLOSEST_HIT 32u
 /* CREATE-time flag, testing only: the members of a device group (config.device_count > 1) all use config.device
  * instead of consecutive devices, so that the group's decomposition and gather run on a single-GPU machine. */
 #define MI355RT_FLAG_GROUP_SHARES_DEVICE 16u
@@ -88,7 +95,7 @@ typedef struct mi355rt_scene_desc {
 
 typedef struct mi355rt_config {
     uint32_t width, height;          /* create_raytracer(.., width, height), lib.rs:15 */
-    uint32_t triangles_per_leaf;     /* accepted for API parity; the BVH uses its own leaf size */
+    uint32_t triangles_per_leaf;     /* leaf size of the reference's octree (the BVH underneath has its own) */
     uint32_t recursions;             /* RECURSIONS = 2, mod.rs:81 (0 selects the default) */
     uint32_t spread;                 /* SUB_SPREAD = 1, mod.rs:82 (0 selects the default) */
     uint32_t flags;                  /* MI355RT_FLAG_* */
@@ -197,8 +204,9 @@ uint32_t mi355rt_get_slices(const mi355rt_handle* h);
 /* Intersector::intersect_ray, accel_intersect.rs:10-13, batched on the device: rays6 = n x
  * (pos3, dir3); out tuv = n x 3 (untouched on a miss), prim = n global triangle indices
  * (0xFFFFFFFF on a miss; geometry_index = tri_geom[prim], vertex_index = 3 * index within
- * the geometry, mod.rs:17-21).  Returns the TRUE closest hit (no_acceleration_intersector.rs
- * semantics: lowest t, ties to the lowest triangle index). */
+ * the geometry, mod.rs:17-21).  Semantics of the handle's intersector (see the flags above): by default the
+ * reference's OctTreeIntersector, with MI355RT_FLAG_TRUE_CLOSEST_HIT the true closest hit (lowest t, ties to
+ * the lowest triangle index). */
 int mi355rt_intersect_rays(mi355rt_handle* h, const float* rays6, size_t n, float* tuv, uint32_t* prim);
 /* shadow-ray predicate of shade(), mod.rs:222-230: blocked[i] = 1 iff the closest hit of ray i
  * has 0.01 < t < 1.0 */
@@ -221,9 +229,10 @@ int mi355rt_debug_slab(mi355rt_handle* h, const float* inv_rays6, const float* c
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
 
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,
- * [4] node bytes, [5] triangle bytes, [6], [7] reserved (0) */
+ * [4] node bytes, [5] triangle bytes, [6] host BVH build time inside create (microseconds), [7] host octree build
+ * time inside create (microseconds; 0 with MI355RT_FLAG_TRUE_CLOSEST_HIT) */
 int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8]);
-/* reference-exact mode only: out[0] octree nodes, [1] inner, [2] leaves, [3] empty leaves, [4] depth,
+/* the reference's octree (absent with MI355RT_FLAG_TRUE_CLOSEST_HIT): out[0] octree nodes, [1] inner, [2] leaves, [3] empty leaves, [4] depth,
  * [5] triangle references (the quantities of SURVEY.md 6.2) */
 int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8]);
 /* devices of the handle's group (1 for an ordinary handle) */

@@ -30,6 +30,7 @@ FLAG_COUNT_STEPS = 2
 FLAG_TIME_KERNELS = 4
 FLAG_OCTREE_SEMANTICS = 8
 FLAG_GROUP_SHARES_DEVICE = 16
+FLAG_TRUE_CLOSEST_HIT = 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
@@ -373,7 +374,7 @@ class RayTracer:
         out = np.zeros(8, np.uint32)
         self._check(lib().mi355rt_accel_stats(self._h, _up(out)))
         return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), max_leaf=int(out[3]),
-                    node_bytes=int(out[4]), tri_bytes=int(out[5]))
+                    node_bytes=int(out[4]), tri_bytes=int(out[5]), bvh_build_ms=int(out[6]) / 1000.0, octree_build_ms=int(out[7]) / 1000.0)
 
     def octree_stats(self):
         out = np.zeros(8, np.uint32)

@@ -278,7 +278,7 @@ int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8])
     const Bvh& b = h->r->bvh;
     out[0] = (uint32_t)b.nodes.size(); out[1] = b.leaves; out[2] = b.max_depth; out[3] = b.max_leaf;
     out[4] = (uint32_t)(b.nodes.size() * sizeof(BvhNode)); out[5] = (uint32_t)(b.tris.size() * sizeof(BvhTri));
-    out[6] = 0; out[7] = 0;
+    out[6] = (uint32_t)(h->r->build_ms_[0] * 1000.0); out[7] = (uint32_t)(h->r->build_ms_[1] * 1000.0);
     return MI355RT_OK;
 }
 int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8])

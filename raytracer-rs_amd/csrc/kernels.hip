@@ -205,7 +205,11 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
 // ---- trace: closest hit of every ray of a round --------------------------------------------------
 // The trace loop of one wave.  SINGLE == false: persistent wave of trace_kernel, pulls chunks from `cursor`.
 // SINGLE == true: the wave traces exactly the rays of chunk `single_chunk` (fused_pass_kernel).
-template <bool PRIMARY, bool COUNT, bool SINGLE, bool STASH>
+// CONFIRM == true (reference-default semantics): shadow rays are traced like radiance rays — closest hit on [0, 1) —
+// and every ray only records its hit; the octree confirm step (confirm_chunk) turns true closest hits into the reference
+// intersector's answers and settles the shadow predicate.  CONFIRM == false (MI355RT_FLAG_TRUE_CLOSEST_HIT): the shadow
+// predicate is decided here with the interval trick of traverse.hpp and unblocked light terms are stored directly.
+template <bool PRIMARY, bool COUNT, bool SINGLE, bool CONFIRM>
 __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam, const DPass& ps,
                                            const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                            float4* __restrict__ hits, uint32_t* cursor,
@@ -276,14 +280,14 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     const float4 r0 = *(const float4*)(p0 + (r << 4)), r1 = *(const float4*)(p1 + (r << 4));
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
                     rec = r;
-                    if (shadow) {       // keep what the finish needs in registers: no load when the ray ends
+                    if (!CONFIRM && shadow) {       // keep what the finish needs in registers: no load when the ray ends
                         const char* __restrict__ p2 = (const char*)(in_q + 2 * ps.qstride);
                         sh_L4 = *(const float4*)(p2 + (r << 4));
                         rec = __float_as_uint(r1.z);           // float index of its light term in slot_L (shade kernel)
                     }
                 }
                 ray_init(rs, o, d, shadow, sc.root);
-                if (shadow) { rs.t = sh_L4.x; rs.u = sh_L4.y; rs.v = sh_L4.z; }
+                if (!CONFIRM && shadow) { rs.t = sh_L4.x; rs.u = sh_L4.y; rs.v = sh_L4.z; }
             }
             w_next += min((uint32_t)__popcll(idle), avail);
             idle = __ballot(rs.node == kNodeIdle);
@@ -298,17 +302,17 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
 #pragma unroll
         for (int u = 0; u < kInnerStepsPerIteration; ++u) {
             if (__ballot(lane_at_inner(rs)) == 0ull) break;
-            inner_pred<COUNT, STASH>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_nodes);
+            inner_pred<COUNT>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_nodes);
             if (COUNT) ++acc_ie;
         }
-        const unsigned long long m_leaf = __ballot(STASH ? lane_has_leaf_work(rs) : lane_at_leaf(rs));
+        const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
-            { leaf_pred<COUNT, STASH>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_tris); if (COUNT) ++acc_le; }
+            { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_tris); if (COUNT) ++acc_le; }
         const bool fin = rs.node == kNodeFin;
         if (__ballot(fin) != 0ull) {
             if (fin) {
                 rs.node = kNodeIdle;
-                if (rs.occ < 0) {                                               // radiance ray
+                if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
                     *(uint32_t*)((char*)ps.hit_prim + (rec << 2)) = rs.prim;     // 4 B for every ray, the 16 B record only for hits
                     if (rs.prim != kMiss) *(float4*)((char*)hits + (rec << 4)) = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
                 } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
@@ -333,7 +337,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
     }
 }
 
-template <bool PRIMARY, bool COUNT, bool STASH>
+template <bool PRIMARY, bool COUNT, bool CONFIRM>
 __global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       float4* __restrict__ hits, uint32_t* cursor,
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene s
                                                       DCounters* counters)
 {
     extern __shared__ int s_stack[];                 // ps.stack_depth rows of kBlock ints
-    trace_wave<PRIMARY, COUNT, false, STASH>(sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters, &s_stack[threadIdx.x], 0u, 0u, 0u);
+    trace_wave<PRIMARY, COUNT, false, CONFIRM>(sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters, &s_stack[threadIdx.x], 0u, 0u, 0u);
 }
 
 // ---- trace with the reference-exact octree intersector (parity path, MI355RT_FLAG_OCTREE_SEMANTICS) ----
@@ -382,12 +386,89 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
     }
 }
 
-// ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
 // The wave's LDS list of hit indices: contiguous (shade_kernel) or spread over the wave's 64 columns of the
 // block's traversal-stack rows (fused_pass_kernel, where the same LDS serves both phases).
 struct LinearList { uint32_t* p; __device__ __forceinline__ uint32_t& operator[](uint32_t i) const { return p[i]; } };
 struct ColumnList { int* col0; __device__ __forceinline__ uint32_t& operator[](uint32_t i) const { return *(uint32_t*)&col0[(i >> 6) * kBlock + (i & 63u)]; } };
 
+// ---- octree confirm: true closest hits -> the reference intersector's answers (traverse.hpp, confirm_walk) --------
+// One wave per chunk, after the trace of a round.  Records that hit something are compacted into the wave's LDS list
+// (ballot + prefix popcount), then every lane walks the octree for one of them.  Radiance records: the hit record is
+// rewritten where the reference's octree returns something else (another triangle, or nothing).  Shadow records: the
+// predicate of mod.rs:226-232 on the confirmed hit; the light term the record carries is stored when the ray is NOT blocked
+// — also for the shadow rays that hit nothing at all.
+template <bool PRIMARY, class List>
+__device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t chunk, const List list,
+                                              const float4* __restrict__ in_q, uint32_t n_rad, uint32_t n_sh,
+                                              float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
+{
+    const int lane = lane_id();
+    if (PRIMARY) {
+        n_rad = min(ps.chunk, ps.nsamples - chunk * ps.chunk); n_sh = 0u;
+        if (chunk_is_culled(cam, ps, chunk, n_rad)) return;                 // nothing was traced, nothing was hit
+    }
+    const uint32_t n_tot = n_rad + n_sh;
+    uint32_t cnt = 0u;
+    for (uint32_t it = 0; it < n_tot; it += 64u) {
+        const uint32_t i = it + (uint32_t)lane;
+        const bool valid = i < n_tot;
+        const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
+        const bool hit = valid && ps.hit_prim[r] != kMiss;
+        if (!PRIMARY && valid && !hit && i >= n_rad) {                       // a shadow ray that hit nothing: not blocked
+            const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
+            float* dst = slot_L + __float_as_uint(r1.z);
+            dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+        }
+        uint32_t n_new;
+        const uint32_t pos = wave_append(hit, cnt, n_new);
+        if (hit) list[pos] = i;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = 0; j < cnt; j += 64u) {
+        if (j + (uint32_t)lane >= cnt) continue;
+        const uint32_t i = list[j + (uint32_t)lane];
+        const uint32_t r = (uint32_t)record_index(ps, chunk, i, n_rad);
+        f3 o, d;
+        if (PRIMARY) {
+            uint32_t pixel, sampleno;
+            primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
+        } else {
+            const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
+            o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+        }
+        const float4 h = hits[r];
+        float t = h.x, u = h.y, v = h.z; uint32_t prim = __float_as_uint(h.w);
+        const uint32_t prim_in = prim;
+        confirm_walk(sc, o, d, t, u, v, prim);
+        if (i < n_rad) {
+            if (prim != prim_in) {
+                ps.hit_prim[r] = prim;
+                if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
+            }
+        } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {               // not blocked, mod.rs:226-232
+            const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
+            float* dst = slot_L + __float_as_uint(r1.z);
+            dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(kBlock) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                                         float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
+{
+    extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.region record indices
+    const LinearList list{ &s_list[(threadIdx.x >> 6) * ps.region] };
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+    for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
+        uint32_t n_rad = 0u, n_sh = 0u;
+        if (!PRIMARY) { const uint2 n = in_counts[chunk]; n_rad = n.x; n_sh = n.y; }
+        confirm_chunk<PRIMARY>(sc, cam, ps, chunk, list, in_q, n_rad, n_sh, hits, slot_L, film_n);
+    }
+}
+
+// ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
 // Shade the hits of one chunk (one wave): see the header of this file.
 // in_nrad: radiance rays of the chunk in in_q (ignored for PRIMARY); out_nrad / out_nshadow: what was appended to out_q.
 template <bool PRIMARY, class List>
@@ -691,6 +772,7 @@ __device__ __forceinline__ void resolve_chunk_1spp(const DPass& ps, uint32_t wid
     }
 }
 
+template <bool CONFIRM>
 __global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera cam, DPass ps, float4* q0, float4* q1, uint2* c0, uint2* c1,
                                                             float4* hits, float* slot_L, uint32_t* sample_slot,
                                                             float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters)
@@ -704,14 +786,16 @@ __global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera c
         // ray counts of the chunk travel from phase to phase in registers: a wave-uniform load of the count the wave
         // itself stored a moment ago would go through the scalar cache, which may hold the line from a neighbour's read
         uint32_t n_rad = 0u, n_sh = 0u;
-        trace_wave<true, false, true, false>(sc, cam, ps, nullptr, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, 0u, 0u);
+        trace_wave<true, false, true, true>(sc, cam, ps, nullptr, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, 0u, 0u);
         phase_fence();
+        if (CONFIRM) { confirm_chunk<true>(sc, cam, ps, chunk, list, nullptr, 0u, 0u, hits, slot_L, film_n); phase_fence(); }
         shade_chunk<true>(sc, cam, ps, 0u, chunk, list, nullptr, 0u, n_rad, n_sh, hits, q0, c0, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
         phase_fence();
         for (uint32_t r = 1; r < ps.recursions + 2u; ++r) {
             float4* in_q = (r - 1u) & 1u ? q1 : q0;
-            trace_wave<false, false, true, false>(sc, cam, ps, in_q, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, n_rad, n_sh);
+            trace_wave<false, false, true, CONFIRM>(sc, cam, ps, in_q, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, n_rad, n_sh);
             phase_fence();
+            if (CONFIRM) { confirm_chunk<false>(sc, cam, ps, chunk, list, in_q, n_rad, n_sh, hits, slot_L, film_n); phase_fence(); }
             if (r <= ps.recursions) {
                 unsigned long long unused = 0;
                 uint32_t o_rad = 0u, o_sh = 0u;
@@ -746,7 +830,9 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const uint32_t* __restrict
 }
 
 // ---- batched Intersector seam (accel_intersect.rs:10-13) --------------------------------------
-__global__ __launch_bounds__(kBlock) void intersect_kernel(DScene sc, const float* __restrict__ rays6, uint32_t n, int shadow_mode,
+// mode 0: BVH true closest hit + octree confirm (reference-default semantics); 1: the reference's octree walked
+// directly (cross-check path); 2: BVH true closest hit only (NoAccelerationIntersector semantics)
+__global__ __launch_bounds__(kBlock) void intersect_kernel(DScene sc, const float* __restrict__ rays6, uint32_t n, int shadow_mode, int mode,
                                                           float* tuv, uint32_t* prim, uint8_t* blocked)
 {
     extern __shared__ int s_stack[];
@@ -754,7 +840,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(DScene sc, const floa
     if (i >= n) return;
     const f3 o = mk3(rays6[6ull * i], rays6[6ull * i + 1], rays6[6ull * i + 2]);
     const f3 d = mk3(rays6[6ull * i + 3], rays6[6ull * i + 4], rays6[6ull * i + 5]);
-    if (sc.oct_nodes) {          // reference-exact intersector
+    if (mode == 1) {             // reference-exact intersector, walked directly
         float t, u, v; uint32_t p;
         octree_intersect(sc, o, d, t, u, v, p);
         if (shadow_mode) blocked[i] = (p != kMiss && t > 0.01f && t < 1.0f) ? 1 : 0;
@@ -766,6 +852,20 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(DScene sc, const floa
     }
     RayState rs;
     uint32_t a = 0, b = 0;
+    if (mode == 0) {
+        // closest hit (shadow rays: on [0, 1)), then the reference's octree decides what it would have returned
+        ray_init(rs, o, d, false, sc.root);
+        if (shadow_mode) rs.tlimit = 0x1.fffffep-1f;
+        ray_run<false>(sc, rs, &s_stack[threadIdx.x], kBlock, a, b);
+        float t = rs.t, u = rs.u, v = rs.v; uint32_t p = rs.prim;
+        if (p != kMiss) confirm_walk(sc, o, d, t, u, v, p);
+        if (shadow_mode) blocked[i] = (p != kMiss && t > 0.01f && t < 1.0f) ? 1 : 0;
+        else {
+            prim[i] = p;
+            if (p != kMiss) { tuv[3ull * i] = t; tuv[3ull * i + 1] = u; tuv[3ull * i + 2] = v; }
+        }
+        return;
+    }
     ray_init(rs, o, d, shadow_mode != 0, sc.root);
     ray_run<false>(sc, rs, &s_stack[threadIdx.x], kBlock, a, b);
     if (shadow_mode) blocked[i] = rs.occ == 1 ? 1 : 0;
@@ -837,7 +937,7 @@ hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, u
 // ---- launchers --------------------------------------------------------------------------------
 static size_t stack_bytes(uint32_t depth) { return (size_t)((depth ? depth : 1u) + 1u) * kBlock * sizeof(int); }   // + one trash row
 
-template <bool P, bool C, bool S>
+template <bool P, bool C, bool F>
 static int trace_blocks_per_cu(size_t lds)
 {
     // the occupancy query costs ~0.3 ms of host time: ask once per (kernel, LDS size)
@@ -845,39 +945,38 @@ static int trace_blocks_per_cu(size_t lds)
     static int cached_nb = 0;
     if (cached_lds != lds) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<P, C, S>, kBlock, lds) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<P, C, F>, kBlock, lds) != hipSuccess || nb < 1) nb = 1;
         cached_nb = nb > 8 ? 8 : nb;
         cached_lds = lds;
     }
     return cached_nb;
 }
 
-template <bool P, bool C, bool S>
+template <bool P, bool C, bool F>
 static hipError_t launch_trace_variant(hipStream_t stream, int num_cus, const DScene& sc, const DCamera& cam, const DPass& ps,
                                        const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
                                        float* slot_L, const uint32_t* film_n, DCounters* counters)
 {
     // persistent grid: as many blocks as the chip holds; waves pull chunks from `cursor`
     const size_t lds = stack_bytes(ps.stack_depth);
-    const int per_cu = trace_blocks_per_cu<P, C, S>(lds);
+    const int per_cu = trace_blocks_per_cu<P, C, F>(lds);
     int use_per_cu = per_cu;
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= per_cu) use_per_cu = v; }   // occupancy experiment
-    hipLaunchKernelGGL((trace_kernel<P, C, S>), dim3((unsigned)(num_cus * use_per_cu)), dim3(kBlock), lds, stream, sc, cam, ps,
+    hipLaunchKernelGGL((trace_kernel<P, C, F>), dim3((unsigned)(num_cus * use_per_cu)), dim3(kBlock), lds, stream, sc, cam, ps,
                        (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n, counters);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, bool stash, const DScene& sc, const DCamera& cam, const DPass& ps,
+// confirm: the octree confirm step follows (reference-default semantics); primary rays are radiance rays either way
+hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
                         const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
                         float* slot_L, const uint32_t* film_n, DCounters* counters)
 {
-#define MI355RT_TRACE_CASE(P, C, S) if (primary == P && count == C && stash == S) return launch_trace_variant<P, C, S>(stream, num_cus, sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters)
-    MI355RT_TRACE_CASE(true, false, false); MI355RT_TRACE_CASE(false, false, false);
-    MI355RT_TRACE_CASE(true, true, false); MI355RT_TRACE_CASE(false, true, false);
-    MI355RT_TRACE_CASE(true, false, true); MI355RT_TRACE_CASE(false, false, true);
-    MI355RT_TRACE_CASE(true, true, true); MI355RT_TRACE_CASE(false, true, true);
-#undef MI355RT_TRACE_CASE
-    return hipErrorInvalidValue;
+#define MI355RT_TRACE_ARGS stream, num_cus, sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters
+    if (primary) return count ? launch_trace_variant<true, true, true>(MI355RT_TRACE_ARGS) : launch_trace_variant<true, false, true>(MI355RT_TRACE_ARGS);
+    if (confirm) return count ? launch_trace_variant<false, true, true>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, true>(MI355RT_TRACE_ARGS);
+    return count ? launch_trace_variant<false, true, false>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, false>(MI355RT_TRACE_ARGS);
+#undef MI355RT_TRACE_ARGS
 }
 
 hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
@@ -951,32 +1050,49 @@ hipError_t launch_place_stripes(hipStream_t stream, const uint32_t* gathered, ui
 }
 
 // rows of LDS the fused kernel needs: the traversal stack (+ trash row) or the wave's hit list, whichever is larger
-uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes)
+uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes, uint32_t records_per_sample)
 {
-    const uint32_t a = (stack_depth ? stack_depth : 1u) + 1u;
-    return a > max_level_nodes ? a : max_level_nodes;
+    const uint32_t a = (stack_depth ? stack_depth : 1u) + 1u;      // traversal stack + trash row
+    const uint32_t b = max_level_nodes > records_per_sample ? max_level_nodes : records_per_sample;   // shade hit list / confirm record list (64-sample chunks: one row per record of a sample)
+    return a > b ? a : b;
 }
 
-hipError_t launch_fused_pass(hipStream_t stream, int num_cus, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes,
+hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes, uint32_t records_per_sample,
                              void* q0, void* q1, void* c0, void* c1, void* hits, float* slot_L, uint32_t* sample_slot,
                              float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters)
 {
     if (ps.nchunks == 0) return hipSuccess;
-    const size_t lds = (size_t)fused_pass_lds_rows(ps.stack_depth, max_level_nodes) * kBlock * sizeof(int);
+    const size_t lds = (size_t)fused_pass_lds_rows(ps.stack_depth, max_level_nodes, records_per_sample) * kBlock * sizeof(int);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned cap = (unsigned)num_cus * 8u;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(fused_pass_kernel, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1, (uint2*)c0, (uint2*)c1,
-                       (float4*)hits, slot_L, sample_slot, film_sum, film_sumsq, film_n, counters);
+    if (confirm) hipLaunchKernelGGL(fused_pass_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1, (uint2*)c0, (uint2*)c1,
+                                    (float4*)hits, slot_L, sample_slot, film_sum, film_sumsq, film_n, counters);
+    else hipLaunchKernelGGL(fused_pass_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1, (uint2*)c0, (uint2*)c1,
+                            (float4*)hits, slot_L, sample_slot, film_sum, film_sumsq, film_n, counters);
     return hipGetLastError();
 }
 
-hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack_depth, const float* rays6, uint32_t n, bool shadow_mode,
+// the octree confirm step of one round (reference-default semantics), between its trace and its shade launch
+hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
+                          const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n)
+{
+    const size_t lds = (size_t)ps.region * kWavesPerBlock * sizeof(uint32_t);
+    unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned cap = (unsigned)num_cus * 8u;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (primary) hipLaunchKernelGGL(confirm_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);
+    else hipLaunchKernelGGL(confirm_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack_depth, int mode, const float* rays6, uint32_t n, bool shadow_mode,
                             float* tuv, uint32_t* prim, uint8_t* blocked)
 {
     if (n == 0) return hipSuccess;
     dim3 block(kBlock), grid((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(intersect_kernel, grid, block, stack_bytes(stack_depth), stream, sc, rays6, n, shadow_mode ? 1 : 0, tuv, prim, blocked);
+    hipLaunchKernelGGL(intersect_kernel, grid, block, stack_bytes(stack_depth), stream, sc, rays6, n, shadow_mode ? 1 : 0, mode, tuv, prim, blocked);
     return hipGetLastError();
 }
 

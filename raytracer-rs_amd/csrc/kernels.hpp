@@ -6,7 +6,7 @@
 
 namespace mi355rt {
 
-hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, bool stash, const DScene& sc, const DCamera& cam, const DPass& ps,
+hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
                         const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
                         float* slot_L, const uint32_t* film_n, DCounters* counters);
 hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
@@ -17,14 +17,17 @@ hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DSc
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color);
 // one 50-row frame (1 sample per pixel) in a single launch: every wave takes a 64-sample chunk through all rounds
-uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes);
-hipError_t launch_fused_pass(hipStream_t stream, int num_cus, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes,
+uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes, uint32_t records_per_sample);
+// reference-default semantics: true closest hits of a round -> the octree intersector's answers (+ the shadow predicate)
+hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
+                          const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n);
+hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes, uint32_t records_per_sample,
                              void* q0, void* q1, void* c0, void* c1, void* hits, float* slot_L, uint32_t* sample_slot,
                              float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters);
 // rows == null: the contiguous rows row_base .. row_base + nrows - 1
 hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t row_base, uint32_t nrows, uint32_t width, bool packed,
                           const float* film_sum, const uint32_t* film_n, uint32_t* out);
-hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack_depth, const float* rays6, uint32_t n, bool shadow_mode,
+hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack_depth, int mode, const float* rays6, uint32_t n, bool shadow_mode,
                             float* tuv, uint32_t* prim, uint8_t* blocked);
 // multi-GPU gather on the root: world slots of slot_rows packed rows each -> full frame
 hipError_t launch_place_stripes(hipStream_t stream, const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height,

@@ -131,6 +131,9 @@ void build_octree(const float* tri_verts, uint32_t ntri, uint32_t tris_per_leaf,
             f.first_child = (int32_t)b.nodes[i].child[0];
         }
     }
+    // parents are written in a second pass (a child's record is cleared when its own turn comes in the loop above)
+    for (size_t i = 0; i < b.nodes.size(); ++i)
+        if (!b.nodes[i].leaf) for (int k = 0; k < 8; ++k) out.nodes[b.nodes[i].child[k]].parent = (uint32_t)i;
     depth_rec(b.nodes, 0, 0, out);
 }
 

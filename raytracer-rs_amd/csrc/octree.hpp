@@ -13,7 +13,8 @@ namespace mi355rt {
 struct alignas(16) OctNodeFlat {
     float cmin[3]; int32_t first_child;     // >= 0: inner node (children first_child .. first_child+7); -1: leaf
     float cmax[3]; uint32_t tri_first;      // leaf: range in Octree::leaf_tris
-    uint32_t tri_count; uint32_t pad[3];
+    uint32_t tri_count; uint32_t parent;    // parent node index (root: 0) — lets the confirm walk climb without a stack
+    uint32_t pad[2];
 };
 static_assert(sizeof(OctNodeFlat) == 48, "octree node must be 48 bytes");
 

@@ -2,6 +2,7 @@
 #include "renderer.hpp"
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,8 +91,8 @@ bool Renderer::set_seed(uint64_t seed)
 // mi355rt_set_flags: run-time flags only; a create-time flag (the intersector) cannot be changed on a live handle
 bool Renderer::set_flags(uint32_t flags)
 {
-    constexpr uint32_t kCreateMask = MI355RT_FLAG_OCTREE_SEMANTICS;
-    if ((flags ^ cfg.flags) & kCreateMask) { last_error = "MI355RT_FLAG_OCTREE_SEMANTICS is a create-time flag: it cannot be changed with mi355rt_set_flags"; return false; }
+    constexpr uint32_t kCreateMask = MI355RT_FLAG_OCTREE_SEMANTICS | MI355RT_FLAG_TRUE_CLOSEST_HIT | MI355RT_FLAG_GROUP_SHARES_DEVICE;
+    if ((flags ^ cfg.flags) & kCreateMask) { last_error = "the intersector flags (OCTREE_SEMANTICS, TRUE_CLOSEST_HIT) are create-time flags: they cannot be changed with mi355rt_set_flags"; return false; }
     cfg.flags = flags;
     return true;
 }
@@ -141,7 +142,9 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     camera = Camera::from_orientation_matrix(cfg.width, cfg.height, Matrix::from_array(scene.cameras[0].orientation), scene.cameras[0].fov_deg);
 
     // --- acceleration structure (host build, once) + per-triangle normals (calc_normal, mod.rs:198-205)
+    const auto t_bvh = std::chrono::steady_clock::now();
     build_bvh(scene.tri_verts.data(), scene.tri_geom.data(), ntri, bvh);
+    build_ms_[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bvh).count();
     collect_cull_boxes();
     if (bvh.max_depth > kBvhMaxDepth) { err = "internal: BVH deeper than the traversal stack"; code = MI355RT_E_INVALID; return false; }
     std::vector<float> normals((size_t)std::max(ntri, 1u) * 4, 0.0f);
@@ -188,10 +191,16 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     dscene_.lights = d_lights; dscene_.textures = d_tex; dscene_.texels = d_texels; dscene_.table = d_table;
     dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri;
     dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr;
-    if (cfg.flags & MI355RT_FLAG_OCTREE_SEMANTICS) {
+    // Intersector semantics.  Default: the reference's default intersector (OctTreeIntersector), served by
+    // the BVH + the octree confirm step.  MI355RT_FLAG_OCTREE_SEMANTICS: the octree walked directly (slow cross-check).
+    // MI355RT_FLAG_TRUE_CLOSEST_HIT: BVH only (NoAccelerationIntersector semantics), no octree is built.
+    mode_ = (cfg.flags & MI355RT_FLAG_OCTREE_SEMANTICS) ? kModeOctreeWalk : (cfg.flags & MI355RT_FLAG_TRUE_CLOSEST_HIT) ? kModeTrueClosest : kModeConfirm;
+    if (mode_ != kModeTrueClosest) {
         // the reference's own structure (OctTreeIntersector::with_triangles_per_leaf, OCT:66-81)
         Octree oct;
+        const auto t_oct = std::chrono::steady_clock::now();
         build_octree(scene.tri_verts.data(), ntri, cfg.triangles_per_leaf, oct);
+        build_ms_[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_oct).count();
         oct_stats_[0] = (uint32_t)oct.nodes.size(); oct_stats_[1] = oct.inner; oct_stats_[2] = oct.leaves;
         oct_stats_[3] = oct.empty_leaves; oct_stats_[4] = oct.max_depth; oct_stats_[5] = (uint32_t)oct.leaf_tris.size();
         std::vector<BvhTri> prim_tris(std::max(ntri, 1u));
@@ -244,7 +253,6 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     for (uint32_t l = 0; l <= cfg.recursions; ++l) max_level_nodes_ = std::max(max_level_nodes_, level_first[l + 1] - level_first[l]);
     chunk_ = 256;
     if (const char* e = getenv("MI355RT_LEAF_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) leaf_threshold_ = (uint32_t)v; }
-    if (const char* e = getenv("MI355RT_STASH")) stash_ = atoi(e) != 0;
     if (const char* e = getenv("MI355RT_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) chunk_ = (uint32_t)v; }
     code = MI355RT_OK;
     return true;
@@ -325,7 +333,7 @@ DCamera Renderer::device_camera() const
     // Valid only if every corner of the box is in front of the camera; computed in double, widened.
     c.cull_valid = 0;
     std::memset(c.cull_rect, 0, sizeof c.cull_rect);
-    if (!cull_boxes_.empty() && !(cfg.flags & MI355RT_FLAG_OCTREE_SEMANTICS) && !getenv("MI355RT_NO_CULL")) {
+    if (!cull_boxes_.empty() && mode_ != kModeOctreeWalk && !getenv("MI355RT_NO_CULL")) {
         const float* e = c.rot;
         const double m[3][3] = { { e[0], e[1], e[2] }, { e[4], e[5], e[6] }, { e[8], e[9], e[10] } };
         const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
@@ -473,19 +481,21 @@ bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32
         }
         const void* in_q = r == 0 ? nullptr : sl.d_queue[(r - 1) & 1];
         const void* in_c = r == 0 ? nullptr : sl.d_chunk_counts[(r - 1) & 1];
-        const bool balance_dbg = count && getenv("MI355RT_DEBUG_UTIL") && !dscene_.oct_nodes;
+        const bool balance_dbg = count && getenv("MI355RT_DEBUG_UTIL") && mode_ != kModeOctreeWalk;
         if (balance_dbg) {       // load-balance diagnostics of this launch (debug only: synchronises)
             DCounters init{};
             HIP_TRY(hipMemcpy(&init, d_counters_, sizeof init, hipMemcpyDeviceToHost));
             init.t_first_end = ~0ull; init.t_start = ~0ull; init.t_last_end = 0; init.t_sum_end = 0; init.n_waves = 0;
             HIP_TRY(hipMemcpy(d_counters_, &init, sizeof init, hipMemcpyHostToDevice));
         }
-        if (dscene_.oct_nodes)
+        if (mode_ == kModeOctreeWalk)
             HIP_TRY(launch_trace_octree(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
         else
-            HIP_TRY(launch_trace(st, num_cus_, r == 0, count, stash_, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
+            HIP_TRY(launch_trace(st, num_cus_, r == 0, count, mode_ == kModeConfirm, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], st)); ev_used_ += 2; }
         ++launches_;
+        if (mode_ == kModeConfirm)       // true closest hits -> the reference intersector's answers; settles the shadow rays of this round
+            HIP_TRY(launch_confirm(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
         if (balance_dbg) {
             DCounters c0{};
             HIP_TRY(hipStreamSynchronize(st));
@@ -600,8 +610,8 @@ uint32_t Renderer::trace_frame_additive()
     const uint32_t nown = (uint32_t)owned_rows.size();
     const FrameWindow win = frame_window(current_row, cfg.height, cfg.stripe_rows, cfg.stripe_world, cfg.stripe_rank, owned_rows);
     // instrumented / timed / reference-exact-octree calls go through the wavefront rounds (several launches, waits for the device)
-    const bool wavefront = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0 || dscene_.oct_nodes != nullptr
-                           || fused_pass_lds_rows(bvh.max_depth + 1, max_level_nodes_) > 60u || getenv("MI355RT_NO_FUSED");
+    const bool wavefront = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0 || mode_ == kModeOctreeWalk
+                           || fused_pass_lds_rows(bvh.max_depth + 1, max_level_nodes_, records_per_sample_) > 60u || getenv("MI355RT_NO_FUSED");
     if (wavefront) {
         if (!begin_call()) return 0;
         for (uint32_t done = 0; done < win.total; done += nown) {
@@ -630,7 +640,7 @@ uint32_t Renderer::trace_frame_additive()
             while (ev_used_ + 2 > ev_pool_.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { last_error = "hipEventCreate failed"; return 0; } ev_pool_.push_back(ev); }
             (void)hipEventRecord(ev_pool_[ev_used_], stream_);
         }
-        hipError_t e = launch_fused_pass(stream_, num_cus_, dscene_, cam, ps, max_level_nodes_, sl.d_queue[0], sl.d_queue[1], sl.d_chunk_counts[0], sl.d_chunk_counts[1],
+        hipError_t e = launch_fused_pass(stream_, num_cus_, mode_ == kModeConfirm, dscene_, cam, ps, max_level_nodes_, records_per_sample_, sl.d_queue[0], sl.d_queue[1], sl.d_chunk_counts[0], sl.d_chunk_counts[1],
                                          sl.d_hits, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_counters_);
         if (e != hipSuccess) { fail(e, "fused pass launch"); return 0; }
         if (timed) { (void)hipEventRecord(ev_pool_[ev_used_ + 1], stream_); ev_used_ += 2; }
@@ -831,7 +841,7 @@ bool Renderer::intersect(const float* rays6, size_t n, float* tuv, uint32_t* pri
     chk(hipMalloc((void**)&d_blocked, n), "hipMalloc blocked");
     if (ok) chk(hipMemcpyAsync(d_rays, rays6, n * 24, hipMemcpyHostToDevice, stream_), "upload rays");
     if (ok && !shadow) chk(hipMemcpyAsync(d_tuv, tuv, n * 12, hipMemcpyHostToDevice, stream_), "upload tuv");   // misses stay untouched
-    if (ok) chk(launch_intersect(stream_, dscene_, bvh.max_depth + 1, d_rays, (uint32_t)n, shadow, d_tuv, d_prim, d_blocked), "intersect kernel");
+    if (ok) chk(launch_intersect(stream_, dscene_, bvh.max_depth + 1, mode_ == kModeConfirm ? 0 : mode_ == kModeOctreeWalk ? 1 : 2, d_rays, (uint32_t)n, shadow, d_tuv, d_prim, d_blocked), "intersect kernel");
     if (ok && shadow) chk(hipMemcpyAsync(blocked, d_blocked, n, hipMemcpyDeviceToHost, stream_), "download blocked");
     if (ok && !shadow) {
         chk(hipMemcpyAsync(tuv, d_tuv, n * 12, hipMemcpyDeviceToHost, stream_), "download tuv");

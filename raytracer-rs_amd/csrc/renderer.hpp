@@ -62,7 +62,10 @@ public:
     uint32_t nodes_per_sample = 1;
     uint32_t level_first[kMaxLevels + 1] = { 0 };
     std::vector<std::array<float, 6>> cull_boxes_;   // top BVH subtree boxes for primary-chunk culling
-    uint32_t oct_stats_[8] = { 0 };       // reference-exact mode: nodes, inner, leaves, empty, depth, triangle refs
+    uint32_t oct_stats_[8] = { 0 };       // the reference's octree: nodes, inner, leaves, empty, depth, triangle refs
+    double build_ms_[2] = { 0.0, 0.0 };   // host build times inside create: BVH (binned SAH), octree (SAT)
+    enum Mode { kModeConfirm = 0, kModeOctreeWalk = 1, kModeTrueClosest = 2 };
+    Mode mode_ = kModeConfirm;            // intersector semantics, fixed at creation
 
 private:
     Renderer() = default;
@@ -131,7 +134,6 @@ private:
     uint32_t chunk_ = 256;               // primary samples per work chunk
     uint32_t max_level_nodes_ = 1;
     uint32_t leaf_threshold_ = 16;
-    bool stash_ = false;                 // trace kernels postpone leaves (speculative traversal), MI355RT_STASH
     bool alloc_failed_ = false;          // the last ensure_pass_capacity failure was an out-of-memory
     uint32_t records_per_sample_ = 1;
     uint32_t nlights_ = 0;

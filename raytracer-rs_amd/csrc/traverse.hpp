@@ -26,7 +26,6 @@ struct RayState {
     uint32_t tri;          // next triangle of the current leaf
     int sp;
     int occ;               // shadow rays: 0 nothing, 1 blocked, 2 unblocked by a hit at t <= 0.01; radiance rays: -1
-    int pend;              // STASH variant of the persistent loop: a postponed leaf (negative leaf code), 0 = none
     bool shadow;
 };
 
@@ -49,7 +48,7 @@ __device__ __forceinline__ void ray_init(RayState& s, f3 o, f3 d, bool shadow, i
     s.selz = __builtin_signbitf(bz) ? 0x01000302u : 0x03020100u;
     s.tlimit = shadow ? 0x1.fffffep-1f : __builtin_inff();     // shadow: t < 1.0
     s.t = __builtin_inff(); s.u = 0.0f; s.v = 0.0f; s.prim = 0xFFFFFFFFu;
-    s.node = root; s.tri = 0u; s.sp = 0; s.occ = shadow ? 0 : -1; s.shadow = shadow; s.pend = 0;
+    s.node = root; s.tri = 0u; s.sp = 0; s.occ = shadow ? 0 : -1; s.shadow = shadow;
 }
 
 // Slab test of one child box of a 32-byte node (bvh.hpp).  Per axis the two half-precision bounds sit
@@ -178,32 +177,16 @@ constexpr int kNodeIdle = (int)0x80000000u, kNodeFin = (int)0x80000001u;
 __device__ __forceinline__ bool lane_at_inner(const RayState& s) { return s.node >= 0; }
 __device__ __forceinline__ bool lane_at_leaf(const RayState& s) { return (uint32_t)s.node > 0x80000001u; }
 
-// pop for the lanes in `want`: next deferred node, or kNodeFin when the stack is empty.
-// STASH: when the stack is empty but a leaf is still postponed, that leaf is the next node (the ray is only
-// finished when nothing is deferred AND nothing is postponed).
-template <bool STASH>
+// pop for the lanes in `want`: next deferred node, or kNodeFin when the stack is empty
 __device__ __forceinline__ int pop_or_finish(RayState& s, bool want, const int* stack, int stride, int trash_row)
 {
     const bool take = want & (s.sp > 0);
     const int popped = stack[(take ? s.sp - 1 : trash_row) * stride];
     s.sp -= take ? 1 : 0;
-    if (STASH) {
-        const bool use_pend = want & !take & (s.pend != 0);
-        const int r = take ? popped : (use_pend ? s.pend : kNodeFin);
-        s.pend = use_pend ? 0 : s.pend;
-        return r;
-    }
     return take ? popped : kNodeFin;
 }
 
-// STASH ("speculative traversal", Aila & Laine 2009): a lane whose nearer child is a leaf does not stop there and
-// wait for the triangle section — it POSTPONES the leaf (one per lane) and goes on with the other child or the next
-// deferred node, so the inner-node section keeps more lanes busy and the triangle section finds more work per
-// execution.  The triangles of a postponed leaf are tested later, by the same code; until then the ray's interval is
-// not yet shortened by their hits, so a few more nodes are visited.  Results cannot change: every leaf whose box the
-// ray reaches within its FINAL interval is still tested, and the closest hit / the shadow predicate do not depend on
-// the order of the tests (ties go to the lowest triangle index, not to the first one found).
-template <bool COUNT, bool STASH>
+template <bool COUNT>
 __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* stack, int stride, int trash_row, uint32_t& n_nodes)
 {
     const bool pred = s.node >= 0;
@@ -220,34 +203,22 @@ __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* s
     const bool sw = tn1 < tn0;                       // child 1 is nearer
     const bool take1 = h1 & (!h0 | sw);
     const int near_c = take1 ? c1i : c0i, far_c = take1 ? c0i : c1i;
-    const bool both = pred & h0 & h1;
+    const bool push = pred & h0 & h1;
     const bool none = pred & !(h0 | h1);
-    if (STASH) {
-        const bool stash = pred & !none & (near_c < 0) & (s.pend == 0);
-        s.pend = stash ? near_c : s.pend;
-        const bool push = both & !stash;             // postponing the near leaf of two hit children: go straight to the far one
-        const bool pop = none | (stash & !both);
-        stack[(push ? s.sp : trash_row) * stride] = far_c;
-        s.sp += push ? 1 : 0;
-        const int next = pop_or_finish<true>(s, pop, stack, stride, trash_row);
-        s.node = pred ? (pop ? next : (stash ? far_c : near_c)) : s.node;
-    } else {
-        stack[(both ? s.sp : trash_row) * stride] = far_c;
-        s.sp += both ? 1 : 0;
-        const int next = pop_or_finish<false>(s, none, stack, stride, trash_row);
-        s.node = pred ? (none ? next : near_c) : s.node;
-    }
+    stack[(push ? s.sp : trash_row) * stride] = far_c;
+    s.sp += push ? 1 : 0;
+    const int next = pop_or_finish(s, none, stack, stride, trash_row);
+    s.node = pred ? (none ? next : near_c) : s.node;
 }
 
-__device__ __forceinline__ bool lane_has_leaf_work(const RayState& s) { return lane_at_leaf(s) | (s.pend != 0); }
-
-template <bool COUNT, bool STASH>
+// CLOSEST_ONLY (reference-default semantics): every ray wants its closest hit with t <= tlimit — radiance
+// rays start with tlimit = inf, shadow rays with the largest float below 1 (mod.rs:226-229 needs the CLOSEST hit of the
+// reference's intersector, which the octree confirm step derives from the true closest hit).  No occlusion state.
+template <bool COUNT, bool CLOSEST_ONLY>
 __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const int* stack, int stride, int trash_row, uint32_t& n_tris)
 {
-    const bool at_leaf = lane_at_leaf(s);
-    const bool from_pend = STASH ? (!at_leaf & (s.pend != 0)) : false;      // the lane is elsewhere in the tree: test its postponed leaf
-    const bool pred = at_leaf | from_pend;
-    const uint32_t code = ~(uint32_t)(from_pend ? s.pend : s.node);
+    const bool pred = lane_at_leaf(s);
+    const uint32_t code = ~(uint32_t)s.node;
     if (COUNT) n_tris += pred ? 1u : 0u;
     const uint32_t off = pred ? (code >> 3) * 48u : 0u;              // 48-byte triangles, unsigned 32-bit byte offset
     const char* __restrict__ base = (const char*)sc.tris;
@@ -264,21 +235,22 @@ __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const i
     const float t = dot3(v0v2, qvec) * inv_det;
     const bool ok = pred & !(fabsf(det) < 1.1920929e-7f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(t < 0.0f);
     const uint32_t prim = __float_as_uint(t0.w);
-    const bool is_shadow = s.occ >= 0;
-    const bool better = ok & !is_shadow & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
-    s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
-    const bool sh = ok & is_shadow & (t <= s.tlimit);
-    const bool sh_far = sh & (t > 0.01f), sh_near = sh & !(t > 0.01f);
-    s.tlimit = better ? t : (sh_far ? 0.01f : s.tlimit);
-    s.occ = sh_near ? 2 : (sh_far ? 1 : s.occ);
     const bool last = (code & 7u) == 0u;
-    if (STASH) {
-        // a postponed leaf: step it, drop it after its last triangle; the lane's node is untouched unless the ray ends here
-        s.pend = from_pend ? ((last | sh_near) ? 0 : s.pend - 7) : (sh_near ? 0 : s.pend);
-        const int next = pop_or_finish<true>(s, at_leaf & last & !sh_near, stack, stride, trash_row);
-        s.node = sh_near ? kNodeFin : (at_leaf ? (last ? next : s.node - 7) : s.node);
+    if (CLOSEST_ONLY) {
+        const bool better = ok & (t <= s.tlimit) & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
+        s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
+        s.tlimit = better ? t : s.tlimit;
+        const int next = pop_or_finish(s, pred & last, stack, stride, trash_row);
+        s.node = pred ? (last ? next : s.node - 7) : s.node;
     } else {
-        const int next = pop_or_finish<false>(s, pred & last & !sh_near, stack, stride, trash_row);
+        const bool is_shadow = s.occ >= 0;
+        const bool better = ok & !is_shadow & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
+        s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
+        const bool sh = ok & is_shadow & (t <= s.tlimit);
+        const bool sh_far = sh & (t > 0.01f), sh_near = sh & !(t > 0.01f);
+        s.tlimit = better ? t : (sh_far ? 0.01f : s.tlimit);
+        s.occ = sh_near ? 2 : (sh_far ? 1 : s.occ);
+        const int next = pop_or_finish(s, pred & last & !sh_near, stack, stride, trash_row);
         s.node = pred ? (sh_near ? kNodeFin : (last ? next : s.node - 7)) : s.node;
     }
 }
@@ -360,6 +332,121 @@ __device__ inline void octree_intersect(const DScene& sc, f3 o, f3 d, float& out
             }
         }
         for (int i = n - 1; i >= 0; --i) stack[sp++] = idx[i];                 // nearest child is popped first
+    }
+}
+
+// ---- reference-default semantics at BVH speed: the octree CONFIRM walk -------------------------------------------
+// Input: the TRUE closest hit H* = (t*, u*, v*, prim*) of a ray (BVH traversal; lowest t, ties to the lowest triangle
+// index).  Output: what OctTreeIntersector::intersect_ray (OCT:148-206, 240-272) returns for that ray — exact, with no
+// tolerance anywhere.  Why that is possible without repeating the reference's work:
+//   * A ray the BVH finds no hit for hits no triangle at all, so the octree returns None: no walk needed.
+//   * Every triangle hit of the ray has t >= t* (same Moller-Trumbore arithmetic, so the same floats).  A leaf L accepts
+//     its closest hit h only if fl(o + d*t_h) lies in cube(L) (OCT:160-169).  fl(o_k + fl(d_k*t)) is MONOTONE in t, so
+//     if the point at t* is already past the far face of a cube C on some axis in the ray's direction of travel
+//     (d_k > 0 and hp_k(t*) > C.max_k, or d_k < 0 and hp_k(t*) < C.min_k), the point at any t_h >= t* is past it too:
+//     no leaf inside C can accept anything.  Such cubes are skipped, subtree and all.
+//   * A leaf whose list contains prim* has h = H* (H* is the minimum over ALL triangles, ties included: the lists are in
+//     ascending triangle order, OCT:94-146): its answer is the contains test on fl(o + d*t*), nothing else to compute.
+//   * Any other leaf that is reached and not skipped (the hit point sits on or within rounding of a cube boundary: rare)
+//     is scanned like the reference scans it (<= triangles_per_leaf exact tests).
+// The visiting order is the reference's: children that pass the slab test, by ascending (tmin, child index) — the stable
+// sort of OCT:176-185 — first accepting leaf wins.  Child cubes are not loaded: they are the parent's min / mid / max per
+// axis with mid = 0.5 * (max + min), the builder's own expression (OCT:274-313), so the floats are identical.
+__device__ __forceinline__ bool cube_contains(f3 mn, f3 mx, f3 p)        // Cube::contains, OCT:34-45 (inclusive)
+{
+    return !(p.x < mn.x || p.x > mx.x || p.y < mn.y || p.y > mx.y || p.z < mn.z || p.z > mx.z);
+}
+
+__device__ inline void confirm_walk(const DScene& sc, f3 o, f3 d, float& t, float& u, float& v, uint32_t& prim)
+{
+    const float4* __restrict__ nodes = (const float4*)sc.oct_nodes;
+    const f3 inv = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));     // OCT:241-244
+    const f3 hp = add3(o, vscale(d, t));                                               // OCT:164 for H*
+    uint32_t node = 0u;
+    float4 n0 = nodes[0], n1 = nodes[1];
+    f3 mn = mk3(n0.x, n0.y, n0.z), mx = mk3(n1.x, n1.y, n1.z);
+    int first_child = __float_as_int(n0.w);
+    bool resuming = false; float r_t = 0.0f; int r_i = 0;      // after a child returned None: only children with a larger (tmin, index) key
+    for (;;) {
+        bool descend = false;
+        if (first_child < 0) {
+            // ---- leaf (reached => not skippable): what does intersect_leaf_triangles + contains give?
+            const uint32_t tri_first = __float_as_uint(n1.w), tri_count = __float_as_uint(nodes[3u * node + 2u].x);
+            // is prim* in this leaf's (ascending) list?
+            uint32_t lo = 0u, hi = tri_count;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.oct_leaf_tris[tri_first + mid] < prim) lo = mid + 1u; else hi = mid; }
+            if (lo < tri_count && sc.oct_leaf_tris[tri_first + lo] == prim) {
+                if (cube_contains(mn, mx, hp)) return;                      // the leaf's closest hit is H* and it is accepted
+            } else if (tri_count != 0u) {
+                // boundary case: scan the list as the reference does (OCT:249-272, strict `<` keeps the first of equal t)
+                const float4* __restrict__ ptris = (const float4*)sc.prim_tris;
+                bool have = false; float bt = 0.0f, bu = 0.0f, bv = 0.0f; uint32_t bp = 0u;
+                for (uint32_t k = 0; k < tri_count; ++k) {
+                    const uint32_t p = sc.oct_leaf_tris[tri_first + k];
+                    const float4 t0 = ptris[3 * p], t1 = ptris[3 * p + 1], t2 = ptris[3 * p + 2];
+                    const f3 v0 = mk3(t0.x, t0.y, t0.z), v0v1 = mk3(t1.x, t1.y, t1.z), v0v2 = mk3(t2.x, t2.y, t2.z);
+                    const f3 pvec = cross3(d, v0v2);
+                    const float det = dot3(v0v1, pvec);
+                    if (fabsf(det) < 1.1920929e-7f) continue;
+                    const float inv_det = div_rn(1.0f, det);
+                    const f3 tvec = sub3(o, v0);
+                    const float uu = dot3(tvec, pvec) * inv_det;
+                    const f3 qvec = cross3(tvec, v0v1);
+                    const float vv = dot3(d, qvec) * inv_det;
+                    const float tt = dot3(v0v2, qvec) * inv_det;
+                    if (uu < 0.0f || uu > 1.0f) continue;
+                    if (vv < 0.0f || uu + vv > 1.0f) continue;
+                    if (tt < 0.0f) continue;
+                    if (!have || tt < bt) { have = true; bt = tt; bu = uu; bv = vv; bp = p; }
+                }
+                if (have && cube_contains(mn, mx, add3(o, vscale(d, bt)))) { t = bt; u = bu; v = bv; prim = bp; return; }
+            }
+        } else {
+            // ---- inner node: first child, in the reference's order, that passes the slab test, is not skippable and
+            // comes after the resume key.  Planes per axis: min, mid, max.
+            const f3 md = mk3(0.5f * (mx.x + mn.x), 0.5f * (mx.y + mn.y), 0.5f * (mx.z + mn.z));
+            // intersect_cube_inverse_ray (OCT:348-372) per half: (plane - origin) * inverse direction
+            const float tx0 = (mn.x - o.x) * inv.x, tx1 = (md.x - o.x) * inv.x, tx2 = (mx.x - o.x) * inv.x;
+            const float ty0 = (mn.y - o.y) * inv.y, ty1 = (md.y - o.y) * inv.y, ty2 = (mx.y - o.y) * inv.y;
+            const float tz0 = (mn.z - o.z) * inv.z, tz1 = (md.z - o.z) * inv.z, tz2 = (mx.z - o.z) * inv.z;
+            const float lox[2] = { fminf(tx0, tx1), fminf(tx1, tx2) }, hix[2] = { fmaxf(tx0, tx1), fmaxf(tx1, tx2) };
+            const float loy[2] = { fminf(ty0, ty1), fminf(ty1, ty2) }, hiy[2] = { fmaxf(ty0, ty1), fmaxf(ty1, ty2) };
+            const float loz[2] = { fminf(tz0, tz1), fminf(tz1, tz2) }, hiz[2] = { fmaxf(tz0, tz1), fmaxf(tz1, tz2) };
+            // skippable halves: the point at t* is past the half's far face in the direction of travel
+            const bool sx[2] = { (d.x > 0.0f && hp.x > md.x) || (d.x < 0.0f && hp.x < mn.x), (d.x > 0.0f && hp.x > mx.x) || (d.x < 0.0f && hp.x < md.x) };
+            const bool sy[2] = { (d.y > 0.0f && hp.y > md.y) || (d.y < 0.0f && hp.y < mn.y), (d.y > 0.0f && hp.y > mx.y) || (d.y < 0.0f && hp.y < md.y) };
+            const bool sz[2] = { (d.z > 0.0f && hp.z > md.z) || (d.z < 0.0f && hp.z < mn.z), (d.z > 0.0f && hp.z > mx.z) || (d.z < 0.0f && hp.z < md.z) };
+            int best = -1; float best_t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int hx = i & 1, hy = (i >> 1) & 1, hz = (i >> 2) & 1;      // child order of generate_child_cubes, OCT:279-312
+                float tmin = fmaxf(lox[hx], loy[hy]), tmax = fminf(hix[hx], hiy[hy]);
+                tmin = fmaxf(tmin, loz[hz]); tmax = fminf(tmax, hiz[hz]);
+                bool cand = (tmax >= tmin) & (tmax > 0.0f) & !(sx[hx] | sy[hy] | sz[hz]);
+                cand &= !resuming | (tmin > r_t) | ((tmin == r_t) & (i > r_i));
+                if (cand & ((best < 0) | (tmin < best_t))) { best = i; best_t = tmin; }   // ascending i: ties keep the lower index (stable sort)
+            }
+            if (best >= 0) {
+                node = (uint32_t)first_child + (uint32_t)best;
+                mn = mk3(best & 1 ? md.x : mn.x, best & 2 ? md.y : mn.y, best & 4 ? md.z : mn.z);
+                mx = mk3(best & 1 ? mx.x : md.x, best & 2 ? mx.y : md.y, best & 4 ? mx.z : md.z);
+                n0 = nodes[3u * node]; n1 = nodes[3u * node + 1u];
+                first_child = __float_as_int(n0.w);
+                resuming = false;
+                descend = true;
+            }
+        }
+        if (descend) continue;
+        // ---- this node yields None: back to the parent, resume after this child
+        if (node == 0u) { prim = 0xFFFFFFFFu; return; }
+        float my_tmin;
+        (void)cube_slab(mn, mx, o, inv, my_tmin);                          // this child's sort key, recomputed (same expression => same float)
+        const uint32_t parent = __float_as_uint(nodes[3u * node + 2u].y);
+        n0 = nodes[3u * parent]; n1 = nodes[3u * parent + 1u];
+        first_child = __float_as_int(n0.w);
+        r_t = my_tmin; r_i = (int)(node - (uint32_t)first_child); resuming = true;
+        node = parent;
+        mn = mk3(n0.x, n0.y, n0.z); mx = mk3(n1.x, n1.y, n1.z);
     }
 }
 

@@ -48,3 +48,33 @@ def scenes(scene_io):
             cache[name] = scene_io.load_scene_file(os.path.join(SCENES, name + ".scene"))
         return cache[name]
     return get
+
+
+class Semantics:
+    """One intersector semantics on both sides: flags for the HIP library and for the CPU oracle.
+    reference_default: the reference's OctTreeIntersector (library: BVH + octree confirm step; oracle: its octree).
+    octree_walk: the same semantics, the library walking the octree directly (slow cross-check path).
+    true_closest: NoAccelerationIntersector semantics (library: BVH only; oracle: brute force)."""
+
+    def __init__(self, name, gpu, orc):
+        self.name, self.gpu, self.orc = name, gpu, orc
+
+    def __repr__(self):
+        return self.name
+
+
+def _semantics(pkg, oracle, name):
+    return {"reference_default": Semantics(name, 0, 0),
+            "octree_walk": Semantics(name, pkg.FLAG_OCTREE_SEMANTICS, 0),
+            "true_closest": Semantics(name, pkg.FLAG_TRUE_CLOSEST_HIT, oracle.FLAG_BRUTE_FORCE)}[name]
+
+
+@pytest.fixture(params=["reference_default", "true_closest"])
+def sem(request, pkg, oracle):
+    """the two shipped semantics (default + opt-out)"""
+    return _semantics(pkg, oracle, request.param)
+
+
+@pytest.fixture(params=["reference_default", "octree_walk", "true_closest"])
+def sem3(request, pkg, oracle):
+    return _semantics(pkg, oracle, request.param)

@@ -74,9 +74,9 @@ def test_create_raytracer_from_collada_doc_renders_like_the_oracle(pkg, oracle):
                  mat_rgb=np.array([[0.8, 0.1, 0.2]], np.float32), mat_tex=np.zeros(1, np.uint32), lights=light.astype(np.float32), textures=[],
                  camera_matrix=m_cam, camera_fov=np.float32(39.59775))
     w, h, spp = 96, 96, 3
-    rt = pkg.create_raytracer(DOC, pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, seed=2)
-    assert rt.triangle_count == 1
-    for flags, oflags in ((0, oracle.FLAG_BRUTE_FORCE),):
+    for flags, oflags in ((0, 0), (pkg.FLAG_TRUE_CLOSEST_HIT, oracle.FLAG_BRUTE_FORCE)):
+        rt = pkg.create_raytracer(DOC, pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, seed=2, flags=flags)
+        assert rt.triangle_count == 1
         orc = oracle.Oracle(scene, w, h, seed=2, flags=oflags)
         c = rt.render(spp); oc = orc.render(spp, nthreads=4)
         assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
@@ -84,7 +84,7 @@ def test_create_raytracer_from_collada_doc_renders_like_the_oracle(pkg, oracle):
         gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
         assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
         assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
-    # the reference's default intersector on the same document
+    # the direct octree walk on the same document
     rto = pkg.create_raytracer(DOC, pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, seed=2, flags=pkg.FLAG_OCTREE_SEMANTICS)
     orco = oracle.Oracle(scene, w, h, seed=2)
     rto.render(spp); orco.render(spp, nthreads=4)
@@ -98,7 +98,7 @@ def test_variance_and_mean_readout_bit_equal_to_oracle(pkg, scenes, oracle, name
     including the n == 1 case (0/0 = NaN and x/0 = inf exactly where the reference produces them)."""
     w, h = 80, 56
     rt = make(pkg, scenes, name, w, h, seed=3)
-    orc = oracle.Oracle(scenes(name), w, h, seed=3, flags=oracle.FLAG_BRUTE_FORCE)
+    orc = oracle.Oracle(scenes(name), w, h, seed=3)
     rt.render(spp); orc.render(spp, nthreads=8)
     with np.errstate(all="ignore"):
         gv, ov = rt.film.get_estimated_variances(), orc.get_estimated_variances()
@@ -110,12 +110,12 @@ def test_variance_and_mean_readout_bit_equal_to_oracle(pkg, scenes, oracle, name
 
 # ---- (d) BASELINE config 1 ------------------------------------------------------------------------------------
 def test_baseline_config_1_ico2_256x256_1spp(pkg, scenes, oracle):
-    """ico2 256x256 x 1 spp — the one BASELINE config where idx / height == idx / width: GPU == oracle in both
-    intersector modes (true closest hit vs brute force; reference-exact octree vs the oracle's default), and
+    """ico2 256x256 x 1 spp — the one BASELINE config where idx / height == idx / width: GPU == oracle in every
+    intersector mode (default = the reference's octree semantics; true closest hit vs brute force; direct octree walk), and
     through the reference's own entry (six 50-row frames sweep the 256 rows once and wrap)."""
     w = h = 256
     sc = scenes("ico2")
-    for flags, oflags in ((0, oracle.FLAG_BRUTE_FORCE), (pkg.FLAG_OCTREE_SEMANTICS, 0)):
+    for flags, oflags in ((0, 0), (pkg.FLAG_TRUE_CLOSEST_HIT, oracle.FLAG_BRUTE_FORCE), (pkg.FLAG_OCTREE_SEMANTICS, 0)):
         rt = make(pkg, scenes, "ico2", w, h, seed=1, flags=flags)
         orc = oracle.Oracle(sc, w, h, seed=1, flags=oflags)
         c = rt.render(1); oc = orc.render(1, nthreads=8)
@@ -133,7 +133,7 @@ def test_baseline_config_1_ico2_256x256_1spp(pkg, scenes, oracle):
     assert np.array_equal(bits(fixed.film.pixel_datas()[0]), bits(plain.film.pixel_datas()[0]))
     # the drop-in loop on C1
     loop = make(pkg, scenes, "ico2", w, h, seed=1)
-    orc = oracle.Oracle(sc, w, h, seed=1, flags=oracle.FLAG_BRUTE_FORCE)
+    orc = oracle.Oracle(sc, w, h, seed=1)
     for _ in range(6):
         assert loop.trace_frame_additive() == orc.trace_frame_additive() == 50 * w
     assert loop.current_row == orc.current_row == (6 * 50) % h
@@ -148,7 +148,7 @@ def test_dropin_loop_thai2_1024x768_matches_oracle(pkg, scenes, oracle):
     equal the oracle's; rows not sampled yet read back white."""
     w, h = 1024, 768
     rt = make(pkg, scenes, "thai2", w, h, seed=1)
-    orc = oracle.Oracle(scenes("thai2"), w, h, seed=1, flags=oracle.FLAG_BRUTE_FORCE)
+    orc = oracle.Oracle(scenes("thai2"), w, h, seed=1)                       # both sides: the reference's default intersector
     buf = np.empty(w * h, np.uint32)
     for call in range(17):
         assert rt.trace_frame_additive() == 50 * w
@@ -183,7 +183,8 @@ def test_fused_frame_equals_wavefront_rounds(pkg, scenes):
     16-18 owned rows and wraps), other recursion settings, a texture, and height < 50."""
     cases = [("ico2", 200, 120, {}), ("ico3_tex", 96, 70, {}), ("ico2", 120, 130, dict(stripe_rows=4, stripe_rank=1, stripe_world=3)),
              ("4boxes", 64, 20, {}), ("ico2", 64, 64, dict(recursions=3, spread=1)), ("ico2", 64, 64, dict(recursions=1, spread=2)),
-             ("ico2", 33, 7, dict(stripe_rows=2, stripe_rank=0, stripe_world=2))]
+             ("ico2", 33, 7, dict(stripe_rows=2, stripe_rank=0, stripe_world=2)),
+             ("4boxes", 96, 64, dict(flags=32)), ("ico2", 96, 64, dict(flags=32)), ("thai2", 160, 100, {})]      # 32 = FLAG_TRUE_CLOSEST_HIT
     for name, w, h, kw in cases:
         a = make(pkg, scenes, name, w, h, seed=6, **kw)
         b = make(pkg, scenes, name, w, h, seed=6, **kw)
@@ -210,7 +211,7 @@ def test_mixing_render_and_frames_keeps_the_readout_current(pkg, scenes, oracle)
     frames, clears and read-outs and compare every read-out with the oracle's full-frame mapping."""
     name, w, h = "ico2", 72, 130
     rt = make(pkg, scenes, name, w, h, seed=9)
-    orc = oracle.Oracle(scenes(name), w, h, seed=9, flags=oracle.FLAG_BRUTE_FORCE)
+    orc = oracle.Oracle(scenes(name), w, h, seed=9)
     assert np.all(rt.get_tonemapped_pixels() == 0xFFFFFFFF)
     rt.trace_frame_additive(); orc.trace_frame_additive()
     assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
@@ -260,12 +261,14 @@ def test_set_seed_and_set_flags_semantics(pkg, scenes, oracle):
     assert np.array_equal(bits(a.sample_table()), bits(b.sample_table()))
     a.render(2); b.render(2)
     assert np.array_equal(bits(a.film.pixel_datas()[0]), bits(b.film.pixel_datas()[0]))
-    orc = oracle.Oracle(scenes(name), w, h, seed=1, flags=oracle.FLAG_BRUTE_FORCE)
+    orc = oracle.Oracle(scenes(name), w, h, seed=1)
     orc.set_seed(5); orc.render(2, nthreads=4)
     assert np.array_equal(bits(a.film.pixel_datas()[0]), bits(orc.film()[0]))
     # flags
     with pytest.raises(RuntimeError, match="create-time"):
         a.set_flags(pkg.FLAG_OCTREE_SEMANTICS)
+    with pytest.raises(RuntimeError, match="create-time"):
+        a.set_flags(pkg.FLAG_TRUE_CLOSEST_HIT)
     o = make(pkg, scenes, "4boxes", w, h, seed=2, flags=pkg.FLAG_OCTREE_SEMANTICS)
     with pytest.raises(RuntimeError, match="create-time"):
         o.set_flags(pkg.FLAG_COUNT_STEPS)                                    # would clear the octree bit

@@ -30,7 +30,7 @@ def test_device_group_equals_one_device(pkg, scenes, oracle, ndev, w, h):
     grp = make(pkg, scenes, name, w, h, seed=4, device_count=ndev, flags=pkg.FLAG_GROUP_SHARES_DEVICE)
     assert grp.device_count == ndev and one.device_count == 1
     assert list(grp.owned_rows()) == list(range(h))
-    orc = oracle.Oracle(scenes(name), w, h, seed=4, flags=oracle.FLAG_BRUTE_FORCE)
+    orc = oracle.Oracle(scenes(name), w, h, seed=4)
     c1 = one.render(spp); cg = grp.render(spp); oc = orc.render(spp, nthreads=4)
     assert (cg.primary, cg.bounce, cg.shadow, cg.primary_hits) == (c1.primary, c1.bounce, c1.shadow, c1.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
     for a, b in zip(grp.film.pixel_datas(), one.film.pixel_datas()):

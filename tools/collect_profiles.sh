@@ -1,13 +1,17 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): rocprofv3 stats + PMC traffic passes + bench JSONs into gpurun_out/$1
+# Runs on the GPU box (through gpurun): rocprofv3 kernel stats of the bench command + the bench JSON lines (which carry
+# their own rocprofv3 --pmc child passes) into gpurun_out/$1.  tools/publish_profiles.sh copies the summaries to profiles/.
 set -o pipefail
-out=gpurun_out/${1:-r01}
+out=gpurun_out/${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p $out
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --slices 1 > $out/bench_under_rocprof.json 2> $out/err.txt
-echo "stats done"
-timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --slices 1 > /dev/null 2>&1; echo "fetch done"
-timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --slices 1 > /dev/null 2>&1; echo "write done"
-timeout -k 10 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_l2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --slices 1 > /dev/null 2>&1; echo "l2 done"
-python bench.py --steps 5 --warmup 2 > $out/bench.json 2>/dev/null; cut -c1-200 $out/bench.json
-for s in ico2 4boxes; do python bench.py --steps 3 --warmup 1 --no-cpu-baseline --scene $s > $out/bench_$s.json 2>/dev/null; done
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fix-row-index > $out/bench_fix_row_index.json 2>/dev/null
+# 1. kernel stats of the headline command (one slice, so that per-kernel durations mean something)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --slices 1 > $out/bench_under_rocprof.json 2> $out/err_stats.txt; echo "stats done $?"
+# 2. kernel trace of the drop-in loop (timeline: are there host-sync gaps between the launches of a step?)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/dropin_trace -- python3 bench.py --mode dropin --steps 300 --warmup 20 --no-cpu-baseline --no-pmc > $out/dropin_under_rocprof.json 2> $out/err_dropin.txt; echo "dropin trace done $?"
+python3 tools/dropin_timeline.py $out/dropin_trace > $out/dropin_timeline.txt 2>&1; tail -5 $out/dropin_timeline.txt
+# 3. the bench lines themselves
+timeout -k 10 500 python bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/err_bench.txt; echo "bench $?"; cut -c1-300 $out/bench.json
+timeout -k 10 300 python bench.py --mode dropin > $out/dropin.json 2> $out/err_dropin2.txt; echo "dropin $?"; cut -c1-300 $out/dropin.json
+for s in ico2 4boxes; do timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --scene $s > $out/bench_$s.json 2>/dev/null; echo "$s $?"; done
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --fix-row-index > $out/bench_fix_row_index.json 2>/dev/null; echo "fix $?"
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --true-closest-hit > $out/bench_true_closest_hit.json 2>/dev/null; echo "tch $?"
