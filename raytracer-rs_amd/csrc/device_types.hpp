@@ -1,6 +1,7 @@
 // device_types.hpp — plain structs shared by the host renderer and the HIP kernels.
 #pragma once
 #include <cstdint>
+#include <hip/hip_vector_types.h>
 
 namespace mi355rt {
 
@@ -37,6 +38,8 @@ struct DScene {
     const void* oct_nodes;    // OctNodeFlat[] (reference-exact intersector only, else null)
     const uint32_t* oct_leaf_tris;
     const void* prim_tris;    // BvhTri[] in ORIGINAL triangle order (reference-exact intersector only)
+    const int2* oct_info;     // per octree node, what the confirm walk needs in ONE 8-byte load: x = first child (>= 0) or ~tri_first (leaf), y = leaf triangle count
+    const uint32_t* tri_home; // per triangle: the one octree leaf that lists it, or 0xFFFFFFFF when several do
     int32_t root;
     uint32_t nlights;
     uint32_t ntri;

@@ -230,6 +230,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
     // a shadow ray never touches rs.t / rs.u / rs.v (only radiance rays record a hit): they carry its light term
     ray_init(rs, mk3(0, 0, 0), mk3(0, 0, 1), false, sc.root);
     rs.node = kNodeIdle;
+    stack[0] = kNodeFin;                             // sentinel row of this lane's stack column (traverse.hpp, pop_or_finish)
 
     for (;;) {
         // ---- refill idle lanes from the current chunk (pull a new chunk when it runs dry)
@@ -302,12 +303,12 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
 #pragma unroll
         for (int u = 0; u < kInnerStepsPerIteration; ++u) {
             if (__ballot(lane_at_inner(rs)) == 0ull) break;
-            inner_pred<COUNT>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_nodes);
+            inner_pred<COUNT>(sc, rs, stack, kBlock, acc_nodes);
             if (COUNT) ++acc_ie;
         }
         const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
-            { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, (int)ps.stack_depth, acc_tris); if (COUNT) ++acc_le; }
+            { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, acc_tris); if (COUNT) ++acc_le; }
         const bool fin = rs.node == kNodeFin;
         if (__ballot(fin) != 0ull) {
             if (fin) {
@@ -397,6 +398,44 @@ struct ColumnList { int* col0; __device__ __forceinline__ uint32_t& operator[](u
 // rewritten where the reference's octree returns something else (another triangle, or nothing).  Shadow records: the
 // predicate of mod.rs:226-232 on the confirmed hit; the light term the record carries is stored when the ray is NOT blocked
 // — also for the shadow rays that hit nothing at all.
+// one record that hit something: radiance -> rewrite the hit record where the octree answers differently; shadow -> the predicate
+template <bool PRIMARY>
+__device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t r, uint32_t sample_index, bool shadow,
+                                               const float4* __restrict__ in_q, float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
+{
+    f3 o, d;
+    if (PRIMARY) {
+        uint32_t pixel, sampleno;
+        primary_sample(cam, ps, film_n, sample_index, pixel, sampleno, o, d);
+    } else {
+        const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
+        o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+    }
+    const float4 h = hits[r];
+    float t = h.x, u = h.y, v = h.z; uint32_t prim = __float_as_uint(h.w);
+    const uint32_t prim_in = prim;
+    confirm_walk(sc, o, d, t, u, v, prim);
+    if (!shadow) {
+        if (prim != prim_in) {
+            ps.hit_prim[r] = prim;
+            if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
+        }
+    } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {               // not blocked, mod.rs:226-232
+        const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
+        float* dst = slot_L + __float_as_uint(r1.z);
+        dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+    }
+}
+
+// a shadow ray that hit nothing is not blocked: store the light term it carries
+__device__ __forceinline__ void store_unblocked(const DPass& ps, uint32_t r, const float4* __restrict__ in_q, float* __restrict__ slot_L)
+{
+    const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
+    float* dst = slot_L + __float_as_uint(r1.z);
+    dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+}
+
+// confirm step of ONE chunk by one wave (fused_pass_kernel): compact the records that hit something, then walk
 template <bool PRIMARY, class List>
 __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t chunk, const List list,
                                               const float4* __restrict__ in_q, uint32_t n_rad, uint32_t n_sh,
@@ -414,11 +453,7 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
         const bool valid = i < n_tot;
         const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
         const bool hit = valid && ps.hit_prim[r] != kMiss;
-        if (!PRIMARY && valid && !hit && i >= n_rad) {                       // a shadow ray that hit nothing: not blocked
-            const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
-            float* dst = slot_L + __float_as_uint(r1.z);
-            dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
-        }
+        if (!PRIMARY && valid && !hit && i >= n_rad) store_unblocked(ps, r, in_q, slot_L);
         uint32_t n_new;
         const uint32_t pos = wave_append(hit, cnt, n_new);
         if (hit) list[pos] = i;
@@ -427,44 +462,53 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
     for (uint32_t j = 0; j < cnt; j += 64u) {
         if (j + (uint32_t)lane >= cnt) continue;
         const uint32_t i = list[j + (uint32_t)lane];
-        const uint32_t r = (uint32_t)record_index(ps, chunk, i, n_rad);
-        f3 o, d;
-        if (PRIMARY) {
-            uint32_t pixel, sampleno;
-            primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
-        } else {
-            const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
-            o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
-        }
-        const float4 h = hits[r];
-        float t = h.x, u = h.y, v = h.z; uint32_t prim = __float_as_uint(h.w);
-        const uint32_t prim_in = prim;
-        confirm_walk(sc, o, d, t, u, v, prim);
-        if (i < n_rad) {
-            if (prim != prim_in) {
-                ps.hit_prim[r] = prim;
-                if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
-            }
-        } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {               // not blocked, mod.rs:226-232
-            const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
-            float* dst = slot_L + __float_as_uint(r1.z);
-            dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
-        }
+        confirm_record<PRIMARY>(sc, cam, ps, (uint32_t)record_index(ps, chunk, i, n_rad), chunk * ps.chunk + i, i >= n_rad, in_q, hits, slot_L, film_n);
     }
     __builtin_amdgcn_wave_barrier();
 }
 
+// The confirm launch of a round.  A chunk holds ~60-90 records that hit something: walked chunk by chunk, the second
+// batch of 64 lanes of every chunk would be mostly empty.  So a wave collects the hit records of its chunks in ONE LDS
+// list and walks 64 of them whenever it has 64 — across chunk borders (the writes are per record, in place).
 template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                          float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
 {
-    extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.region record indices
-    const LinearList list{ &s_list[(threadIdx.x >> 6) * ps.region] };
+    extern __shared__ uint32_t s_list[];             // per wave: (ps.region + 64) entries of { record index | shadow << 31, sample index }
+    const int lane = lane_id();
+    const uint32_t cap = ps.region + 64u;
+    uint32_t* list_r = &s_list[(threadIdx.x >> 6) * cap * 2u];
+    uint32_t* list_s = list_r + cap;
     const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+    uint32_t cnt = 0u;
     for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
         uint32_t n_rad = 0u, n_sh = 0u;
-        if (!PRIMARY) { const uint2 n = in_counts[chunk]; n_rad = n.x; n_sh = n.y; }
-        confirm_chunk<PRIMARY>(sc, cam, ps, chunk, list, in_q, n_rad, n_sh, hits, slot_L, film_n);
+        if (PRIMARY) {
+            n_rad = min(ps.chunk, ps.nsamples - chunk * ps.chunk);
+            if (chunk_is_culled(cam, ps, chunk, n_rad)) continue;
+        } else { const uint2 n = in_counts[chunk]; n_rad = n.x; n_sh = n.y; }
+        const uint32_t n_tot = n_rad + n_sh;
+        for (uint32_t it = 0; it < n_tot; it += 64u) {
+            const uint32_t i = it + (uint32_t)lane;
+            const bool valid = i < n_tot;
+            const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
+            const bool hit = valid && ps.hit_prim[r] != kMiss;
+            if (!PRIMARY && valid && !hit && i >= n_rad) store_unblocked(ps, r, in_q, slot_L);
+            uint32_t n_new;
+            const uint32_t pos = wave_append(hit, cnt, n_new);
+            if (hit) { list_r[pos] = r | (i >= n_rad ? 0x80000000u : 0u); if (PRIMARY) list_s[pos] = chunk * ps.chunk + i; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (cnt >= 64u) {                          // full batches, taken from the end of the list
+            cnt -= 64u;
+            const uint32_t code = list_r[cnt + (uint32_t)lane];
+            confirm_record<PRIMARY>(sc, cam, ps, code & 0x7FFFFFFFu, PRIMARY ? list_s[cnt + (uint32_t)lane] : 0u, (code >> 31) != 0u, in_q, hits, slot_L, film_n);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if ((uint32_t)lane < cnt) {                       // the last, partial batch
+        const uint32_t code = list_r[lane];
+        confirm_record<PRIMARY>(sc, cam, ps, code & 0x7FFFFFFFu, PRIMARY ? list_s[lane] : 0u, (code >> 31) != 0u, in_q, hits, slot_L, film_n);
     }
 }
 
@@ -935,7 +979,7 @@ hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, u
 }
 
 // ---- launchers --------------------------------------------------------------------------------
-static size_t stack_bytes(uint32_t depth) { return (size_t)((depth ? depth : 1u) + 1u) * kBlock * sizeof(int); }   // + one trash row
+static size_t stack_bytes(uint32_t depth) { return (size_t)((depth ? depth : 1u) + 1u) * kBlock * sizeof(int); }   // sentinel row + one row per level (the deepest level's row doubles as the spare row above the top)
 
 template <bool P, bool C, bool F>
 static int trace_blocks_per_cu(size_t lds)
@@ -1077,9 +1121,9 @@ hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, cons
 hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
                           const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n)
 {
-    const size_t lds = (size_t)ps.region * kWavesPerBlock * sizeof(uint32_t);
+    const size_t lds = (size_t)(ps.region + 64u) * 2u * kWavesPerBlock * sizeof(uint32_t);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned cap = (unsigned)num_cus * 8u;
+    const unsigned cap = (unsigned)num_cus * 6u;          // several chunks per wave, so that batches fill up across chunks
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (primary) hipLaunchKernelGGL(confirm_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);

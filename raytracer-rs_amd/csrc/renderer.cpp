@@ -190,7 +190,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     dscene_.nodes = d_nodes; dscene_.tris = d_tris; dscene_.normals = d_normals; dscene_.materials = d_mats;
     dscene_.lights = d_lights; dscene_.textures = d_tex; dscene_.texels = d_texels; dscene_.table = d_table;
     dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri;
-    dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr;
+    dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr; dscene_.oct_info = nullptr; dscene_.tri_home = nullptr;
     // Intersector semantics.  Default: the reference's default intersector (OctTreeIntersector), served by
     // the BVH + the octree confirm step.  MI355RT_FLAG_OCTREE_SEMANTICS: the octree walked directly (slow cross-check).
     // MI355RT_FLAG_TRUE_CLOSEST_HIT: BVH only (NoAccelerationIntersector semantics), no octree is built.
@@ -215,6 +215,22 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
         if (!upload(d_leaf, oct.leaf_tris.data(), oct.leaf_tris.size() * 4)) return bail();
         if (!upload(d_ptris, prim_tris.data(), prim_tris.size() * sizeof(BvhTri))) return bail();
         dscene_.oct_nodes = d_oct; dscene_.oct_leaf_tris = d_leaf; dscene_.prim_tris = d_ptris;
+        // compact views for the confirm walk
+        std::vector<int2> info(oct.nodes.size());
+        std::vector<uint32_t> home(std::max(ntri, 1u), 0xFFFFFFFEu);               // 0xFFFFFFFE: in no leaf (yet)
+        for (size_t i = 0; i < oct.nodes.size(); ++i) {
+            const OctNodeFlat& f = oct.nodes[i];
+            if (f.first_child >= 0) { info[i].x = f.first_child; info[i].y = 0; continue; }
+            info[i].x = ~(int32_t)f.tri_first; info[i].y = (int32_t)f.tri_count;
+            for (uint32_t k = 0; k < f.tri_count; ++k) {
+                uint32_t& h = home[oct.leaf_tris[f.tri_first + k]];
+                h = h == 0xFFFFFFFEu ? (uint32_t)i : 0xFFFFFFFFu;
+            }
+        }
+        int2* d_info = nullptr; uint32_t* d_home = nullptr;
+        if (!upload(d_info, info.data(), info.size() * sizeof(int2))) return bail();
+        if (!upload(d_home, home.data(), home.size() * 4)) return bail();
+        dscene_.oct_info = d_info; dscene_.tri_home = d_home;
     }
 
     // --- film (film.rs:27-35) and row lists

@@ -135,7 +135,7 @@ __device__ __forceinline__ bool leaf_step(const DScene& sc, RayState& s, const i
         if (!(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && !(t < 0.0f)) {
             const uint32_t prim = __float_as_uint(t0.w);
             if (!s.shadow) {
-                if (s.prim == 0xFFFFFFFFu || t < s.t || (t == s.t && prim < s.prim)) {
+                if (t <= s.tlimit && (s.prim == 0xFFFFFFFFu || t < s.t || (t == s.t && prim < s.prim))) {    // tlimit: inf, the closest hit so far, or (closest-hit shadow rays) just below 1
                     s.t = t; s.u = u; s.v = v; s.prim = prim; s.tlimit = t;
                 }
             } else if (t <= s.tlimit) {
@@ -177,17 +177,20 @@ constexpr int kNodeIdle = (int)0x80000000u, kNodeFin = (int)0x80000001u;
 __device__ __forceinline__ bool lane_at_inner(const RayState& s) { return s.node >= 0; }
 __device__ __forceinline__ bool lane_at_leaf(const RayState& s) { return (uint32_t)s.node > 0x80000001u; }
 
-// pop for the lanes in `want`: next deferred node, or kNodeFin when the stack is empty
-__device__ __forceinline__ int pop_or_finish(RayState& s, bool want, const int* stack, int stride, int trash_row)
+// Stack layout of the persistent loop (lane-major LDS column, row stride `stride`): row 0 holds the SENTINEL kNodeFin,
+// deferred node k sits in row k + 1, s.sp = number of deferred nodes.  A pop reads row sp — the top entry, or the
+// sentinel when nothing is deferred — so "stack empty => ray finished" needs no compare and no select; lanes that do not
+// pop read the same (valid) row and drop the value.  A push writes row sp + 1; lanes that do not push write there too:
+// above the top is free space (one spare row is allocated), so that needs no select either.
+__device__ __forceinline__ int pop_or_finish(RayState& s, bool want, const int* stack, int stride)
 {
-    const bool take = want & (s.sp > 0);
-    const int popped = stack[(take ? s.sp - 1 : trash_row) * stride];
-    s.sp -= take ? 1 : 0;
-    return take ? popped : kNodeFin;
+    const int popped = stack[s.sp * stride];
+    s.sp = max(s.sp - (want ? 1 : 0), 0);
+    return popped;
 }
 
 template <bool COUNT>
-__device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* stack, int stride, int trash_row, uint32_t& n_nodes)
+__device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* stack, int stride, uint32_t& n_nodes)
 {
     const bool pred = s.node >= 0;
     if (COUNT) n_nodes += pred ? 1u : 0u;
@@ -205,9 +208,9 @@ __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* s
     const int near_c = take1 ? c1i : c0i, far_c = take1 ? c0i : c1i;
     const bool push = pred & h0 & h1;
     const bool none = pred & !(h0 | h1);
-    stack[(push ? s.sp : trash_row) * stride] = far_c;
+    stack[(s.sp + 1) * stride] = far_c;              // row above the top: kept only if sp is incremented
     s.sp += push ? 1 : 0;
-    const int next = pop_or_finish(s, none, stack, stride, trash_row);
+    const int next = pop_or_finish(s, none, stack, stride);
     s.node = pred ? (none ? next : near_c) : s.node;
 }
 
@@ -215,7 +218,7 @@ __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* s
 // rays start with tlimit = inf, shadow rays with the largest float below 1 (mod.rs:226-229 needs the CLOSEST hit of the
 // reference's intersector, which the octree confirm step derives from the true closest hit).  No occlusion state.
 template <bool COUNT, bool CLOSEST_ONLY>
-__device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const int* stack, int stride, int trash_row, uint32_t& n_tris)
+__device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const int* stack, int stride, uint32_t& n_tris)
 {
     const bool pred = lane_at_leaf(s);
     const uint32_t code = ~(uint32_t)s.node;
@@ -240,7 +243,7 @@ __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const i
         const bool better = ok & (t <= s.tlimit) & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
         s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
         s.tlimit = better ? t : s.tlimit;
-        const int next = pop_or_finish(s, pred & last, stack, stride, trash_row);
+        const int next = pop_or_finish(s, pred & last, stack, stride);
         s.node = pred ? (last ? next : s.node - 7) : s.node;
     } else {
         const bool is_shadow = s.occ >= 0;
@@ -250,7 +253,7 @@ __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const i
         const bool sh_far = sh & (t > 0.01f), sh_near = sh & !(t > 0.01f);
         s.tlimit = better ? t : (sh_far ? 0.01f : s.tlimit);
         s.occ = sh_near ? 2 : (sh_far ? 1 : s.occ);
-        const int next = pop_or_finish(s, pred & last & !sh_near, stack, stride, trash_row);
+        const int next = pop_or_finish(s, pred & last & !sh_near, stack, stride);
         s.node = pred ? (sh_near ? kNodeFin : (last ? next : s.node - 7)) : s.node;
     }
 }
@@ -363,19 +366,28 @@ __device__ inline void confirm_walk(const DScene& sc, f3 o, f3 d, float& t, floa
     const f3 inv = mk3(div_rn(1.0f, d.x), div_rn(1.0f, d.y), div_rn(1.0f, d.z));     // OCT:241-244
     const f3 hp = add3(o, vscale(d, t));                                               // OCT:164 for H*
     uint32_t node = 0u;
-    float4 n0 = nodes[0], n1 = nodes[1];
-    f3 mn = mk3(n0.x, n0.y, n0.z), mx = mk3(n1.x, n1.y, n1.z);
-    int first_child = __float_as_int(n0.w);
+    const float4 root0 = nodes[0], root1 = nodes[1];
+    f3 mn = mk3(root0.x, root0.y, root0.z), mx = mk3(root1.x, root1.y, root1.z);
+    int2 info = sc.oct_info[0];                               // x: first child (>= 0) or ~tri_first (leaf); y: leaf triangle count
+    const uint32_t home = sc.tri_home[prim];                  // the only leaf that lists prim*, or 0xFFFFFFFF (several)
     bool resuming = false; float r_t = 0.0f; int r_i = 0;      // after a child returned None: only children with a larger (tmin, index) key
+    // (plane - o) * inv can only be NaN when an inverse component is not finite (0 * inf) or the ray itself holds a NaN:
+    // such rays always take the general child scan
+    const bool special = !(fabsf(inv.x) < __builtin_inff()) || !(fabsf(inv.y) < __builtin_inff()) || !(fabsf(inv.z) < __builtin_inff())
+                         || o.x != o.x || o.y != o.y || o.z != o.z;
     for (;;) {
         bool descend = false;
-        if (first_child < 0) {
+        if (info.x < 0) {
             // ---- leaf (reached => not skippable): what does intersect_leaf_triangles + contains give?
-            const uint32_t tri_first = __float_as_uint(n1.w), tri_count = __float_as_uint(nodes[3u * node + 2u].x);
+            const uint32_t tri_first = (uint32_t)~info.x, tri_count = (uint32_t)info.y;
             // is prim* in this leaf's (ascending) list?
-            uint32_t lo = 0u, hi = tri_count;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.oct_leaf_tris[tri_first + mid] < prim) lo = mid + 1u; else hi = mid; }
-            if (lo < tri_count && sc.oct_leaf_tris[tri_first + lo] == prim) {
+            bool member = home == node;
+            if (home == 0xFFFFFFFFu) {
+                uint32_t lo = 0u, hi = tri_count;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.oct_leaf_tris[tri_first + mid] < prim) lo = mid + 1u; else hi = mid; }
+                member = lo < tri_count && sc.oct_leaf_tris[tri_first + lo] == prim;
+            }
+            if (member) {
                 if (cube_contains(mn, mx, hp)) return;                      // the leaf's closest hit is H* and it is accepted
             } else if (tri_count != 0u) {
                 // boundary case: scan the list as the reference does (OCT:249-272, strict `<` keeps the first of equal t)
@@ -416,22 +428,39 @@ __device__ inline void confirm_walk(const DScene& sc, f3 o, f3 d, float& t, floa
             const bool sx[2] = { (d.x > 0.0f && hp.x > md.x) || (d.x < 0.0f && hp.x < mn.x), (d.x > 0.0f && hp.x > mx.x) || (d.x < 0.0f && hp.x < md.x) };
             const bool sy[2] = { (d.y > 0.0f && hp.y > md.y) || (d.y < 0.0f && hp.y < mn.y), (d.y > 0.0f && hp.y > mx.y) || (d.y < 0.0f && hp.y < md.y) };
             const bool sz[2] = { (d.z > 0.0f && hp.z > md.z) || (d.z < 0.0f && hp.z < mn.z), (d.z > 0.0f && hp.z > mx.z) || (d.z < 0.0f && hp.z < md.z) };
-            int best = -1; float best_t = 0.0f;
+            // Fast decision.  Per axis take the allowed half with the smaller entry value lo: the child c0 made of these
+            // halves has the smallest sort key of all candidates (the key is max3 of the per-axis values, and max is
+            // monotone), so no candidate sorts strictly before it.  Another candidate TIES with it exactly when, on some
+            // axis where both halves are allowed, the other half's lo does not exceed c0's key (then the stable sort's
+            // child-index order decides).  No tie, c0 passes the slab test, a ray without inf / NaN in its inverse direction, not
+            // resuming: c0 is the reference's next child.  Anything else: the general scan over all eight children below.
+            const int nx = sx[0] ? 1 : (sx[1] ? 0 : (lox[1] < lox[0] ? 1 : 0));
+            const int ny = sy[0] ? 1 : (sy[1] ? 0 : (loy[1] < loy[0] ? 1 : 0));
+            const int nz = sz[0] ? 1 : (sz[1] ? 0 : (loz[1] < loz[0] ? 1 : 0));
+            const float key0 = fmaxf(fmaxf(nx ? lox[1] : lox[0], ny ? loy[1] : loy[0]), nz ? loz[1] : loz[0]);
+            const float tmax0 = fminf(fminf(nx ? hix[1] : hix[0], ny ? hiy[1] : hiy[0]), nz ? hiz[1] : hiz[0]);
+            const bool none_allowed = (sx[0] & sx[1]) | (sy[0] & sy[1]) | (sz[0] & sz[1]);       // the point at t* is past this whole cube
+            const bool tie = (!sx[0] & !sx[1] & ((nx ? lox[0] : lox[1]) <= key0)) | (!sy[0] & !sy[1] & ((ny ? loy[0] : loy[1]) <= key0))
+                           | (!sz[0] & !sz[1] & ((nz ? loz[0] : loz[1]) <= key0));
+            const bool fast = !resuming & !special & !none_allowed & !tie & (tmax0 >= key0) & (tmax0 > 0.0f);
+            int best = fast ? (nx | (ny << 1) | (nz << 2)) : -1;
+            if (!fast & !none_allowed) {
+                float best_t = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int hx = i & 1, hy = (i >> 1) & 1, hz = (i >> 2) & 1;      // child order of generate_child_cubes, OCT:279-312
-                float tmin = fmaxf(lox[hx], loy[hy]), tmax = fminf(hix[hx], hiy[hy]);
-                tmin = fmaxf(tmin, loz[hz]); tmax = fminf(tmax, hiz[hz]);
-                bool cand = (tmax >= tmin) & (tmax > 0.0f) & !(sx[hx] | sy[hy] | sz[hz]);
-                cand &= !resuming | (tmin > r_t) | ((tmin == r_t) & (i > r_i));
-                if (cand & ((best < 0) | (tmin < best_t))) { best = i; best_t = tmin; }   // ascending i: ties keep the lower index (stable sort)
+                for (int i = 0; i < 8; ++i) {
+                    const int hx = i & 1, hy = (i >> 1) & 1, hz = (i >> 2) & 1;      // child order of generate_child_cubes, OCT:279-312
+                    float tmin = fmaxf(lox[hx], loy[hy]), tmax = fminf(hix[hx], hiy[hy]);
+                    tmin = fmaxf(tmin, loz[hz]); tmax = fminf(tmax, hiz[hz]);
+                    bool cand = (tmax >= tmin) & (tmax > 0.0f) & !(sx[hx] | sy[hy] | sz[hz]);
+                    cand &= !resuming | (tmin > r_t) | ((tmin == r_t) & (i > r_i));
+                    if (cand & ((best < 0) | (tmin < best_t))) { best = i; best_t = tmin; }   // ascending i: ties keep the lower index (stable sort)
+                }
             }
             if (best >= 0) {
-                node = (uint32_t)first_child + (uint32_t)best;
+                node = (uint32_t)info.x + (uint32_t)best;
                 mn = mk3(best & 1 ? md.x : mn.x, best & 2 ? md.y : mn.y, best & 4 ? md.z : mn.z);
                 mx = mk3(best & 1 ? mx.x : md.x, best & 2 ? mx.y : md.y, best & 4 ? mx.z : md.z);
-                n0 = nodes[3u * node]; n1 = nodes[3u * node + 1u];
-                first_child = __float_as_int(n0.w);
+                info = sc.oct_info[node];
                 resuming = false;
                 descend = true;
             }
@@ -442,11 +471,11 @@ __device__ inline void confirm_walk(const DScene& sc, f3 o, f3 d, float& t, floa
         float my_tmin;
         (void)cube_slab(mn, mx, o, inv, my_tmin);                          // this child's sort key, recomputed (same expression => same float)
         const uint32_t parent = __float_as_uint(nodes[3u * node + 2u].y);
-        n0 = nodes[3u * parent]; n1 = nodes[3u * parent + 1u];
-        first_child = __float_as_int(n0.w);
-        r_t = my_tmin; r_i = (int)(node - (uint32_t)first_child); resuming = true;
+        const float4 p0 = nodes[3u * parent], p1 = nodes[3u * parent + 1u];
+        info = sc.oct_info[parent];
+        r_t = my_tmin; r_i = (int)(node - (uint32_t)info.x); resuming = true;
         node = parent;
-        mn = mk3(n0.x, n0.y, n0.z); mx = mk3(n1.x, n1.y, n1.z);
+        mn = mk3(p0.x, p0.y, p0.z); mx = mk3(p1.x, p1.y, p1.z);
     }
 }
 

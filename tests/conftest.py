@@ -12,6 +12,13 @@ SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+    # PyTorch ships its own copy of the HIP runtime: it has to initialise BEFORE libmi355rt.so pulls in /opt/rocm's
+    # (tests that hand torch buffers / streams to the library fail with "no ROCm-capable device" in the other order)
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:       # noqa: BLE001 — CPU-only runs do not need torch
+        pass
 
 
 def _ensure_built():
