@@ -595,3 +595,17 @@ def test_baseline_configs_at_full_size(pkg, scenes, name, spp):
     rt.film.clear(); c2 = rt.render(spp)
     assert (c2.bounce, c2.shadow, c2.primary_hits) == (c.bounce, c.shadow, c.primary_hits)
     assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(s1))
+
+
+def test_build_times_are_reported(pkg, scenes):
+    """mi355rt_accel_stats reports the host build times inside mi355rt_create: the binned-SAH BVH and the reference's
+    octree (SAT).  The API never rebuilds (the scene is fixed at create; camera moves only clear the film), so these are
+    one-off costs: DESIGN.md section 8 quotes the numbers this test prints."""
+    for name, sc in (("thai2", scenes("thai2")), ("random 120 000 triangles", _random_scene(scenes, 120000, 7))):
+        rt = pkg.create_raytracer_from_arrays(sc, 70, 64, 64, seed=1)
+        st = rt.accel_stats(); oc = rt.octree_stats()
+        print("\n[build %s] BVH %.1f ms (%d nodes, depth %d), octree %.1f ms (%d nodes, depth %d, %d triangle references)" % (
+            name, st["bvh_build_ms"], st["nodes"], st["max_depth"], st["octree_build_ms"], oc["nodes"], oc["depth"], oc["tri_refs"]))
+        assert 0.0 < st["bvh_build_ms"] < 5000.0 and 0.0 < st["octree_build_ms"] < 60000.0
+        fast = pkg.create_raytracer_from_arrays(sc, 70, 64, 64, seed=1, flags=pkg.FLAG_TRUE_CLOSEST_HIT)
+        assert fast.accel_stats()["octree_build_ms"] == 0.0 and fast.octree_stats()["nodes"] == 0
