@@ -206,12 +206,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if os.environ.get("MI355RT_BENCH_SHARE_GPU") != "1":
+        torch.cuda.set_device(local_rank)
     dist = None
+    share_gpu = os.environ.get("MI355RT_BENCH_SHARE_GPU") == "1"       # rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, gloo
+    if share_gpu:
+        local_rank = 0
+        torch.cuda.set_device(0)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
     import importlib
