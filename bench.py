@@ -260,6 +260,7 @@ def main():
     cur_stream = torch.cuda.current_stream().cuda_stream
 
     def sync():
+        rt.synchronize()                                           # the library's own streams (frames, the native gather)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -276,7 +277,7 @@ def main():
             rt.tonemap_owned_rows_device(stripe.data_ptr(), rows.size * width, stream=cur_stream)   # ordered on torch's stream
             fg.gather(dist, stripe)
         if time_gather:
-            torch.cuda.synchronize()
+            rt.synchronize(); torch.cuda.synchronize()
             gather_ms.append((time.perf_counter() - t0) * 1e3)
         return counts
 

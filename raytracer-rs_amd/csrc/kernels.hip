@@ -474,13 +474,12 @@ template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                          float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
 {
-    extern __shared__ uint32_t s_list[];             // per wave: (ps.region + 64) entries of { record index | shadow << 31, sample index }
+    __shared__ uint32_t s_list[kWavesPerBlock][2][128];   // per wave: up to 127 pending entries of { record index | shadow << 31, sample index }
     const int lane = lane_id();
-    const uint32_t cap = ps.region + 64u;
-    uint32_t* list_r = &s_list[(threadIdx.x >> 6) * cap * 2u];
-    uint32_t* list_s = list_r + cap;
+    uint32_t* list_r = s_list[threadIdx.x >> 6][0];
+    uint32_t* list_s = s_list[threadIdx.x >> 6][1];
     const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
-    uint32_t cnt = 0u;
+    uint32_t cnt = 0u;                                // < 64 between the steps below
     for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
         uint32_t n_rad = 0u, n_sh = 0u;
         if (PRIMARY) {
@@ -497,14 +496,15 @@ __global__ __launch_bounds__(kBlock) void confirm_kernel(DScene sc, DCamera cam,
             uint32_t n_new;
             const uint32_t pos = wave_append(hit, cnt, n_new);
             if (hit) { list_r[pos] = r | (i >= n_rad ? 0x80000000u : 0u); if (PRIMARY) list_s[pos] = chunk * ps.chunk + i; }
+            __builtin_amdgcn_wave_barrier();
+            if (cnt >= 64u) {                         // a full batch, taken from the end of the list
+                cnt -= 64u;
+                const uint32_t code = list_r[cnt + (uint32_t)lane];
+                const uint32_t si = PRIMARY ? list_s[cnt + (uint32_t)lane] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                confirm_record<PRIMARY>(sc, cam, ps, code & 0x7FFFFFFFu, si, (code >> 31) != 0u, in_q, hits, slot_L, film_n);
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        while (cnt >= 64u) {                          // full batches, taken from the end of the list
-            cnt -= 64u;
-            const uint32_t code = list_r[cnt + (uint32_t)lane];
-            confirm_record<PRIMARY>(sc, cam, ps, code & 0x7FFFFFFFu, PRIMARY ? list_s[cnt + (uint32_t)lane] : 0u, (code >> 31) != 0u, in_q, hits, slot_L, film_n);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     if ((uint32_t)lane < cnt) {                       // the last, partial batch
         const uint32_t code = list_r[lane];
@@ -1121,7 +1121,7 @@ hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, cons
 hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
                           const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n)
 {
-    const size_t lds = (size_t)(ps.region + 64u) * 2u * kWavesPerBlock * sizeof(uint32_t);
+    const size_t lds = 0;                                  // the pending lists are static LDS (128 entries per wave)
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned cap = (unsigned)num_cus * 6u;          // several chunks per wave, so that batches fill up across chunks
     if (blocks > cap) blocks = cap;
