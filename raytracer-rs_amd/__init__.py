@@ -33,7 +33,7 @@ FLAG_GROUP_SHARES_DEVICE = 16
 FLAG_TRUE_CLOSEST_HIT = 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
+LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(_HERE, "libmi355rt.so")     # MI355RT_LIB: an A/B build of the library
 _lib = None
 
 
