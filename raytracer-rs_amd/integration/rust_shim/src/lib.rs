@@ -140,6 +140,10 @@ fn build_raytracer(scene: Scene, triangles_per_leaf: usize, width: usize, height
     unsafe { mi355rt_default_config(&mut cfg) };
     cfg.width = width as u32; cfg.height = height as u32; cfg.triangles_per_leaf = triangles_per_leaf as u32;
     cfg.seed = std::time::SystemTime::now().duration_since(std::time::UNIX_EPOCH).map(|d| d.as_nanos() as u64).unwrap_or(1);
+    // cfg.flags = 0: the library intersects with the reference's DEFAULT intersector semantics (OctTreeIntersector built
+    // with triangles_per_leaf, as lib.rs:29-44 wires it), exactly.  cfg.device_count > 1 spreads the rows over that many
+    // GPUs of this process; the RayTracer stays one object.
+    if let Ok(n) = std::env::var("MI355RT_GPUS") { if let Ok(n) = n.parse::<u32>() { cfg.device_count = n.max(1); } }
 
     let mut h: *mut mi355rt_handle = std::ptr::null_mut();
     let rc = unsafe { mi355rt_create(&desc, &cfg, &mut h) };
