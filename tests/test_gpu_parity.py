@@ -609,3 +609,50 @@ def test_build_times_are_reported(pkg, scenes):
         assert 0.0 < st["bvh_build_ms"] < 5000.0 and 0.0 < st["octree_build_ms"] < 60000.0
         fast = pkg.create_raytracer_from_arrays(sc, 70, 64, 64, seed=1, flags=pkg.FLAG_TRUE_CLOSEST_HIT)
         assert fast.accel_stats()["octree_build_ms"] == 0.0 and fast.octree_stats()["nodes"] == 0
+
+
+def _adversarial_rays(sc, rng, n):
+    """Rays aimed at the places where the octree semantics are NOT the true closest hit and where the confirm step leaves
+    its fast path: origins and hit points ON the octree's grid planes (root bounds, mid planes of the first four levels),
+    axis-parallel and in-plane directions (inf / NaN in the inverse direction), rays through cube corners and along cube
+    edges, rays starting on triangle vertices, plus ordinary random rays."""
+    v = sc["tri_verts"].reshape(-1, 3).astype(np.float32)
+    lo, hi = v.min(0), v.max(0)
+    grid = [np.unique(np.concatenate([np.linspace(lo[a], hi[a], 2 ** k + 1, dtype=np.float32) for k in range(5)])) for a in range(3)]
+    def on_grid(m):
+        p = rng.uniform(lo, hi, (m, 3)).astype(np.float32)
+        for a in range(3):
+            sel = rng.random(m) < 0.6
+            p[sel, a] = rng.choice(grid[a], int(sel.sum()))
+        return p
+    parts = []
+    m = n // 6
+    o = on_grid(m); t = on_grid(m); parts.append(np.concatenate([o, t - o], 1))                       # grid point -> grid point
+    o = on_grid(m); d = np.zeros((m, 3), np.float32); ax = rng.integers(0, 3, m); d[np.arange(m), ax] = rng.choice([-1.0, 1.0], m); parts.append(np.concatenate([o - 20 * d * (rng.random((m, 1)) < 0.5), d], 1))   # axis-parallel
+    o = on_grid(m); d = rng.normal(size=(m, 3)).astype(np.float32); d[np.arange(m), rng.integers(0, 3, m)] = 0.0; parts.append(np.concatenate([o, d], 1))   # in-plane
+    tv = v[rng.integers(0, len(v), m)]; o = rng.uniform(lo - 3, hi + 3, (m, 3)).astype(np.float32); parts.append(np.concatenate([o, tv - o], 1))          # through triangle vertices
+    tv = v[rng.integers(0, len(v), m)]; d = rng.normal(size=(m, 3)).astype(np.float32); parts.append(np.concatenate([tv, d], 1))                           # starting on vertices
+    o = rng.uniform(lo - 3, hi + 3, (n - 5 * m, 3)).astype(np.float32); t = rng.uniform(lo, hi, (n - 5 * m, 3)).astype(np.float32); parts.append(np.concatenate([o, t - o], 1))
+    return np.concatenate(parts).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,tpl", [("4boxes", 70), ("4boxes", 5), ("ico2", 70), ("ico2", 1), ("thai2", 70), ("thai2", 8)])
+def test_confirm_step_equals_direct_octree_walk_on_adversarial_rays(pkg, scenes, name, tpl):
+    """The shipped default (BVH + octree confirm step) against the direct walk of the reference's octree, on the device, for
+    300 000 rays built to sit on the octree's grid planes, corners and edges and on triangle vertices: identical hit records
+    (triangle, t, u, v bit for bit) and identical shadow predicates.  (Both against the oracle: the parametrised seam tests.)"""
+    sc = scenes(name)
+    rng = np.random.default_rng(12345 + tpl)
+    rays = _adversarial_rays(sc, rng, 300000)
+    a = make(pkg, scenes, name, 32, 32, triangles_per_leaf=tpl)
+    b = make(pkg, scenes, name, 32, 32, triangles_per_leaf=tpl, flags=pkg.FLAG_OCTREE_SEMANTICS)
+    ta, pa = a.intersect_rays(rays); tb, pb = b.intersect_rays(rays)
+    assert np.array_equal(pa, pb), "hit triangles differ for %d rays" % int((pa != pb).sum())
+    m = pa != 0xFFFFFFFF
+    assert m.sum() > 20000 and np.array_equal(bits(ta[m]), bits(tb[m]))
+    assert np.array_equal(a.occluded_rays(rays), b.occluded_rays(rays))
+    # and the true closest hit differs from both somewhere (otherwise this test would not exercise the semantics)
+    c = make(pkg, scenes, name, 32, 32, flags=pkg.FLAG_TRUE_CLOSEST_HIT)
+    _, pc = c.intersect_rays(rays)
+    print("\n[adversarial %s, %d per leaf] rays whose octree answer is not the true closest hit: %d of %d" % (name, tpl, int((pc != pa).sum()), len(rays)))
+    assert (pc != pa).sum() > 0
