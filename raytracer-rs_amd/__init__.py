@@ -20,6 +20,7 @@ no CPU fallback here: if the shared library is missing, importing `lib()` raises
 import ctypes as C
 import os
 import time
+import weakref
 
 import numpy as np
 
@@ -237,8 +238,10 @@ class RayTracer:
         L = lib()
         self.width = L.mi355rt_width(self._h)
         self.height = L.mi355rt_height(self._h)
-        self.camera = Camera(self)
-        self.film = Film(self)
+        # weak back-references: no reference cycle, so dropping the last reference to a RayTracer destroys the handle (and
+        # frees its tens of GB of pass buffers) at once instead of whenever the cycle collector runs
+        self.camera = Camera(weakref.proxy(self))
+        self.film = Film(weakref.proxy(self))
 
     def close(self):
         if self._h:
