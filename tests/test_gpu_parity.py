@@ -658,3 +658,45 @@ def test_confirm_step_equals_direct_octree_walk_on_adversarial_rays(pkg, scenes,
     _, pc = c.intersect_rays(rays)
     print("\n[adversarial %s, %d per leaf] rays whose octree answer is not the true closest hit: %d of %d" % (name, tpl, int((pc != pa).sum()), len(rays)))
     assert (pc != pa).sum() > 0
+
+
+def test_randomised_configurations_match_oracle(pkg, scenes, oracle):
+    """24 random configurations — scene, image size, seed, camera pose, samples, recursion / spread, octree leaf size,
+    semantics, stripes, row-index fix, whole frames mixed with 50-row frames — each compared with the oracle bit for bit
+    (film sums, sums of squares, counts, packed pixels).  A fixed generator seed keeps the test reproducible."""
+    rng = np.random.default_rng(20261004)
+    names = ["4boxes", "ico2", "ico3_tex", "thai2"]
+    for case in range(24):
+        name = names[int(rng.integers(0, 4))]
+        w, h = int(rng.integers(17, 140)), int(rng.integers(9, 110))
+        seed = int(rng.integers(1, 1 << 30))
+        rec, spread = [(2, 1), (2, 1), (1, 1), (0, 1), (1, 2), (3, 1)][int(rng.integers(0, 6))]
+        tpl = int(rng.choice([1, 3, 10, 70, 200]))
+        closest = bool(rng.integers(0, 3) == 0)
+        fix = bool(rng.integers(0, 2))
+        world = int(rng.choice([1, 1, 2, 3])); rank = int(rng.integers(0, world)); srows = int(rng.choice([1, 4, 8]))
+        gflags = (pkg.FLAG_TRUE_CLOSEST_HIT if closest else 0) | (pkg.FLAG_FIX_ROW_INDEX if fix else 0)
+        oflags = (oracle.FLAG_BRUTE_FORCE if closest else 0) | (oracle.FLAG_FIX_ROW_INDEX if fix else 0)
+        rt = pkg.create_raytracer_from_arrays(scenes(name), tpl, w, h, seed=seed, recursions=rec, spread=spread, flags=gflags,
+                                              stripe_rows=srows, stripe_rank=rank, stripe_world=world)
+        orc = oracle.Oracle(scenes(name), w, h, tris_per_leaf=tpl, recursions=rec, spread=spread, seed=seed, flags=oflags)
+        for _ in range(int(rng.integers(0, 4))):
+            mv = rng.uniform(-0.3, 0.3, 3).astype(np.float32); ax, ay = np.float32(rng.uniform(-0.1, 0.1)), np.float32(rng.uniform(-0.1, 0.1))
+            rt.camera.move_rel(float(mv[0]), float(mv[1]), float(mv[2])); orc.camera_move_rel(float(mv[0]), float(mv[1]), float(mv[2]))
+            rt.camera.add_x_angle(float(ax)); orc.camera_add_x_angle(float(ax))
+            rt.camera.add_y_angle(float(ay)); orc.camera_add_y_angle(float(ay))
+        rows = rt.owned_rows()
+        desc = (case, name, w, h, seed, rec, spread, tpl, closest, fix, world, rank, srows)
+        for step in range(int(rng.integers(1, 4))):
+            if world == 1 and rng.integers(0, 2) == 0:
+                assert rt.trace_frame_additive() == orc.trace_frame_additive(), desc      # the oracle has no stripes: frames only on whole handles
+            else:
+                spp = int(rng.integers(1, 4))
+                rt.render(spp)
+                for r0 in rows:                                                          # the oracle renders exactly the owned rows
+                    orc.render(spp, nthreads=1, rows=(int(r0), int(r0) + 1))
+        gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+        m = np.zeros(h, bool); m[rows] = True; m = np.repeat(m, w)
+        assert np.array_equal(gn[m], on[m]), desc
+        assert np.array_equal(bits(gs[m]), bits(os_[m])) and np.array_equal(bits(gq[m]), bits(oq[m])), desc
+        assert np.array_equal(rt.get_tonemapped_pixels()[m], orc.get_tonemapped_pixels()[m]), desc
