@@ -471,7 +471,7 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
 // batch of 64 lanes of every chunk would be mostly empty.  So a wave collects the hit records of its chunks in ONE LDS
 // list and walks 64 of them whenever it has 64 — across chunk borders (the writes are per record, in place).
 template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+__global__ __launch_bounds__(kBlock, 7) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                          float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
 {
     __shared__ uint32_t s_list[kWavesPerBlock][2][128];   // per wave: up to 127 pending entries of { record index | shadow << 31, sample index }
@@ -1123,7 +1123,7 @@ hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const D
 {
     const size_t lds = 0;                                  // the pending lists are static LDS (128 entries per wave)
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned cap = (unsigned)num_cus * 6u;          // several chunks per wave, so that batches fill up across chunks
+    const unsigned cap = (unsigned)num_cus * 7u;          // several chunks per wave, so that batches fill up across chunks
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (primary) hipLaunchKernelGGL(confirm_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);
