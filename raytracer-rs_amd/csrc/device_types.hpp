@@ -43,6 +43,8 @@ struct DScene {
     int32_t root;
     uint32_t nlights;
     uint32_t ntri;
+    uint32_t oct_single_leaf; // the reference's octree is one leaf (scene of <= triangles_per_leaf triangles): the trace kernels settle its semantics themselves
+    float oct_root[6];        // root cube of the octree (scene extents): min.xyz, max.xyz
 };
 
 struct DCamera {

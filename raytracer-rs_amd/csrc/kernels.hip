@@ -202,6 +202,14 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
     return i < n_rad ? base + i : base + (ps.region - 1u - (i - n_rad));
 }
 
+// a shadow ray that hit nothing is not blocked: store the light term it carries
+__device__ __forceinline__ void store_unblocked(const DPass& ps, uint32_t r, const float4* __restrict__ in_q, float* __restrict__ slot_L)
+{
+    const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
+    float* dst = slot_L + __float_as_uint(r1.z);
+    dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+}
+
 // ---- trace: closest hit of every ray of a round --------------------------------------------------
 // The trace loop of one wave.  SINGLE == false: persistent wave of trace_kernel, pulls chunks from `cursor`.
 // SINGLE == true: the wave traces exactly the rays of chunk `single_chunk` (fused_pass_kernel).
@@ -313,6 +321,20 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         if (__ballot(fin) != 0ull) {
             if (fin) {
                 rs.node = kNodeIdle;
+                if (CONFIRM && sc.oct_single_leaf) {
+                    // The reference's octree is ONE leaf (at most triangles_per_leaf triangles in the scene, e.g. 4boxes): the leaf
+                    // lists every triangle, so its closest hit IS the true closest hit and the octree's whole answer is the
+                    // contains test of OCT:160-169 on the root cube.  Settled right here: no confirm launch for such scenes.
+                    bool hit = rs.prim != kMiss;
+                    if (hit) hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]),
+                                                 add3(rs.o, vscale(rs.d, rs.t)));
+                    if (rs.occ < 0) {                                           // radiance ray
+                        *(uint32_t*)((char*)ps.hit_prim + (rec << 2)) = hit ? rs.prim : kMiss;
+                        if (hit) *(float4*)((char*)hits + (rec << 4)) = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
+                    } else if (!(hit && rs.t > 0.01f && rs.t < 1.0f)) {          // shadow ray, not blocked (mod.rs:226-232)
+                        store_unblocked(ps, rec, in_q, slot_L);
+                    }
+                } else
                 if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
                     *(uint32_t*)((char*)ps.hit_prim + (rec << 2)) = rs.prim;     // 4 B for every ray, the 16 B record only for hits
                     if (rs.prim != kMiss) *(float4*)((char*)hits + (rec << 4)) = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
@@ -425,14 +447,6 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
         float* dst = slot_L + __float_as_uint(r1.z);
         dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
     }
-}
-
-// a shadow ray that hit nothing is not blocked: store the light term it carries
-__device__ __forceinline__ void store_unblocked(const DPass& ps, uint32_t r, const float4* __restrict__ in_q, float* __restrict__ slot_L)
-{
-    const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
-    float* dst = slot_L + __float_as_uint(r1.z);
-    dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
 }
 
 // confirm step of ONE chunk by one wave (fused_pass_kernel): compact the records that hit something, then walk
@@ -832,14 +846,14 @@ __global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera c
         uint32_t n_rad = 0u, n_sh = 0u;
         trace_wave<true, false, true, true>(sc, cam, ps, nullptr, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, 0u, 0u);
         phase_fence();
-        if (CONFIRM) { confirm_chunk<true>(sc, cam, ps, chunk, list, nullptr, 0u, 0u, hits, slot_L, film_n); phase_fence(); }
+        if (CONFIRM && !sc.oct_single_leaf) { confirm_chunk<true>(sc, cam, ps, chunk, list, nullptr, 0u, 0u, hits, slot_L, film_n); phase_fence(); }
         shade_chunk<true>(sc, cam, ps, 0u, chunk, list, nullptr, 0u, n_rad, n_sh, hits, q0, c0, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
         phase_fence();
         for (uint32_t r = 1; r < ps.recursions + 2u; ++r) {
             float4* in_q = (r - 1u) & 1u ? q1 : q0;
             trace_wave<false, false, true, CONFIRM>(sc, cam, ps, in_q, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, n_rad, n_sh);
             phase_fence();
-            if (CONFIRM) { confirm_chunk<false>(sc, cam, ps, chunk, list, in_q, n_rad, n_sh, hits, slot_L, film_n); phase_fence(); }
+            if (CONFIRM && !sc.oct_single_leaf) { confirm_chunk<false>(sc, cam, ps, chunk, list, in_q, n_rad, n_sh, hits, slot_L, film_n); phase_fence(); }
             if (r <= ps.recursions) {
                 unsigned long long unused = 0;
                 uint32_t o_rad = 0u, o_sh = 0u;

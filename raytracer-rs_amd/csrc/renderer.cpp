@@ -190,7 +190,8 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     dscene_.nodes = d_nodes; dscene_.tris = d_tris; dscene_.normals = d_normals; dscene_.materials = d_mats;
     dscene_.lights = d_lights; dscene_.textures = d_tex; dscene_.texels = d_texels; dscene_.table = d_table;
     dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri;
-    dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr; dscene_.oct_info = nullptr; dscene_.tri_home = nullptr;
+    dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr; dscene_.oct_info = nullptr; dscene_.tri_home = nullptr; dscene_.oct_single_leaf = 0u;
+    std::memset(dscene_.oct_root, 0, sizeof dscene_.oct_root);
     // Intersector semantics.  Default: the reference's default intersector (OctTreeIntersector), served by
     // the BVH + the octree confirm step.  MI355RT_FLAG_OCTREE_SEMANTICS: the octree walked directly (slow cross-check).
     // MI355RT_FLAG_TRUE_CLOSEST_HIT: BVH only (NoAccelerationIntersector semantics), no octree is built.
@@ -231,6 +232,8 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
         if (!upload(d_info, info.data(), info.size() * sizeof(int2))) return bail();
         if (!upload(d_home, home.data(), home.size() * 4)) return bail();
         dscene_.oct_info = d_info; dscene_.tri_home = d_home;
+        dscene_.oct_single_leaf = (mode_ == kModeConfirm && oct.nodes.size() == 1) ? 1u : 0u;
+        for (int a = 0; a < 3; ++a) { dscene_.oct_root[a] = oct.nodes[0].cmin[a]; dscene_.oct_root[3 + a] = oct.nodes[0].cmax[a]; }
     }
 
     // --- film (film.rs:27-35) and row lists
@@ -510,7 +513,7 @@ bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32
             HIP_TRY(launch_trace(st, num_cus_, r == 0, count, mode_ == kModeConfirm, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], st)); ev_used_ += 2; }
         ++launches_;
-        if (mode_ == kModeConfirm)       // true closest hits -> the reference intersector's answers; settles the shadow rays of this round
+        if (mode_ == kModeConfirm && !dscene_.oct_single_leaf)   // true closest hits -> the reference intersector's answers; settles the shadow rays of this round (one-leaf octrees: done in the trace kernel)
             HIP_TRY(launch_confirm(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
         if (balance_dbg) {
             DCounters c0{};
