@@ -41,6 +41,13 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 #ifndef MI355RT_FUSED_FENCE_AGENT
 #define MI355RT_FUSED_FENCE_AGENT 0
 #endif
+#ifndef MI355RT_CONFIRM_BLOCKS
+#define MI355RT_CONFIRM_BLOCKS 5               // blocks per CU the confirm kernel is compiled for (A/B knob, profiles/r02_notes.md)
+#endif
+#ifndef MI355RT_CONFIRM_PULL
+#define MI355RT_CONFIRM_PULL 0                 // 0: like the trace kernel (ps.pull_mode); 2: static striding (A/B knob)
+#endif
+constexpr uint32_t kConfirmPullMode = MI355RT_CONFIRM_PULL;
 constexpr bool kFusedFenceAgent = MI355RT_FUSED_FENCE_AGENT != 0;      // A/B knob of the build (see phase_fence)
 constexpr int kInnerStepsPerIteration = 2;     // measured: 1 -> 2 takes 9 % off the trace kernel, 3 and 4 add nothing
 
@@ -436,7 +443,9 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
     const float4 h = hits[r];
     float t = h.x, u = h.y, v = h.z; uint32_t prim = __float_as_uint(h.w);
     const uint32_t prim_in = prim;
+#ifndef MI355RT_EXP_NOWALK          // timing experiment (wrong results): the confirm kernel's gathers and stores without the walk
     confirm_walk(sc, o, d, t, u, v, prim);
+#endif
     if (!shadow) {
         if (prim != prim_in) {
             ps.hit_prim[r] = prim;
@@ -485,16 +494,17 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
 // batch of 64 lanes of every chunk would be mostly empty.  So a wave collects the hit records of its chunks in ONE LDS
 // list and walks 64 of them whenever it has 64 — across chunk borders (the writes are per record, in place).
 template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock, 7) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
-                                                         float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
+__global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
+                                                         float4* __restrict__ hits, uint32_t* cursor, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
 {
     __shared__ uint32_t s_list[kWavesPerBlock][2][128];   // per wave: up to 127 pending entries of { record index | shadow << 31, sample index }
     const int lane = lane_id();
     uint32_t* list_r = s_list[threadIdx.x >> 6][0];
     uint32_t* list_s = s_list[threadIdx.x >> 6][1];
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
     uint32_t cnt = 0u;                                // < 64 between the steps below
-    for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
+    // chunks are pulled like the trace kernel pulls them (the hits sit in a part of the image: static striding leaves waves idle)
+    PullState pull; uint32_t chunk = 0u;
+    while (pull_chunk(cursor, ps.nchunks, kConfirmPullMode ? kConfirmPullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
         uint32_t n_rad = 0u, n_sh = 0u;
         if (PRIMARY) {
             n_rad = min(ps.chunk, ps.nsamples - chunk * ps.chunk);
@@ -1133,15 +1143,15 @@ hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, cons
 
 // the octree confirm step of one round (reference-default semantics), between its trace and its shade launch
 hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
-                          const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n)
+                          const void* in_q, const void* in_counts, void* hits, uint32_t* cursor, float* slot_L, const uint32_t* film_n)
 {
     const size_t lds = 0;                                  // the pending lists are static LDS (128 entries per wave)
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned cap = (unsigned)num_cus * 7u;          // several chunks per wave, so that batches fill up across chunks
+    const unsigned cap = (unsigned)num_cus * MI355RT_CONFIRM_BLOCKS;   // several chunks per wave, so that batches fill up across chunks
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    if (primary) hipLaunchKernelGGL(confirm_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);
-    else hipLaunchKernelGGL(confirm_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, slot_L, film_n);
+    if (primary) hipLaunchKernelGGL(confirm_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n);
+    else hipLaunchKernelGGL(confirm_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n);
     return hipGetLastError();
 }
 

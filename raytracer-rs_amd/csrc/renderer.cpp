@@ -514,7 +514,7 @@ bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32
         if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], st)); ev_used_ += 2; }
         ++launches_;
         if (mode_ == kModeConfirm && !dscene_.oct_single_leaf)   // true closest hits -> the reference intersector's answers; settles the shadow rays of this round (one-leaf octrees: done in the trace kernel)
-            HIP_TRY(launch_confirm(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
+            HIP_TRY(launch_confirm(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound + kConfirmCursorOffset, sl.d_slot_L, d_film_n_));
         if (balance_dbg) {
             DCounters c0{};
             HIP_TRY(hipStreamSynchronize(st));

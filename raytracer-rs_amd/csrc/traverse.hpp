@@ -375,8 +375,48 @@ __device__ inline void confirm_walk(const DScene& sc, f3 o, f3 d, float& t, floa
     // such rays always take the general child scan
     const bool special = !(fabsf(inv.x) < __builtin_inff()) || !(fabsf(inv.y) < __builtin_inff()) || !(fabsf(inv.z) < __builtin_inff())
                          || o.x != o.x || o.y != o.y || o.z != o.z;
+    // Mirrored frame for the fast descent: every axis on which the ray travels in the negative direction is negated
+    // (cube, origin, hit point, inverse direction), so that the ray travels in the positive direction on all three.
+    // Negation is exact and (-p - -o) * -inv == (p - o) * inv bit for bit, so every plane distance and every comparison
+    // below is the reference's own; 0.5 * (-mn + -mx) == -(0.5 * (mx + mn)) likewise.
+    const bool px = !(d.x < 0.0f), py = !(d.y < 0.0f), pz = !(d.z < 0.0f);
+    const f3 om = mk3(px ? o.x : -o.x, py ? o.y : -o.y, pz ? o.z : -o.z);
+    const f3 hpm = mk3(px ? hp.x : -hp.x, py ? hp.y : -hp.y, pz ? hp.z : -hp.z);
+    const f3 invm = mk3(px ? inv.x : -inv.x, py ? inv.y : -inv.y, pz ? inv.z : -inv.z);
     for (;;) {
         bool descend = false;
+        if (!special && !resuming && info.x >= 0) {
+            // ---- fast descent.  In the mirrored frame the near half of every axis is the low one.  Per axis: the low half is
+            // skippable iff the point at t* lies beyond the mid plane; if it lies beyond the far face the whole node is.  The
+            // child c0 of the nearest allowed halves has the smallest sort key of all candidates; another candidate ties with
+            // it iff, on an axis where both halves are allowed, the mid-plane distance (= c0's exit distance on that axis)
+            // does not exceed c0's key.  No tie and c0 passes the slab test: c0 is the reference's next child.  Everything
+            // else (tie, failing slab test, node wholly passed) leaves the loop for the general code below.
+            f3 a = mk3(px ? mn.x : -mx.x, py ? mn.y : -mx.y, pz ? mn.z : -mx.z);
+            f3 b = mk3(px ? mx.x : -mn.x, py ? mx.y : -mn.y, pz ? mx.z : -mn.z);
+            for (;;) {
+                const f3 md = mk3(0.5f * (b.x + a.x), 0.5f * (b.y + a.y), 0.5f * (b.z + a.z));
+                const bool lx = hpm.x > md.x, ly = hpm.y > md.y, lz = hpm.z > md.z;          // low half skippable
+                const bool gone = (hpm.x > b.x) | (hpm.y > b.y) | (hpm.z > b.z);              // every child skippable
+                const f3 nr = mk3(lx ? md.x : a.x, ly ? md.y : a.y, lz ? md.z : a.z);          // chosen half: near plane ...
+                const f3 fr = mk3(lx ? b.x : md.x, ly ? b.y : md.y, lz ? b.z : md.z);          // ... and far plane
+                const float tnx = (nr.x - om.x) * invm.x, tny = (nr.y - om.y) * invm.y, tnz = (nr.z - om.z) * invm.z;
+                const float tfx = (fr.x - om.x) * invm.x, tfy = (fr.y - om.y) * invm.y, tfz = (fr.z - om.z) * invm.z;
+                const float key0 = fmaxf(fmaxf(tnx, tny), tnz), tmax0 = fminf(fminf(tfx, tfy), tfz);
+                const bool tie = (!lx & (tfx <= key0)) | (!ly & (tfy <= key0)) | (!lz & (tfz <= key0));
+                if (gone | tie | !(tmax0 >= key0) | !(tmax0 > 0.0f)) break;
+                const uint32_t ci = (uint32_t)(lx == px) | ((uint32_t)(ly == py) << 1) | ((uint32_t)(lz == pz) << 2);   // real child index: high half iff (mirrored high) == (not mirrored)
+                node = (uint32_t)info.x + ci;
+                a = nr; b = fr;
+                info = sc.oct_info[node];
+                if (info.x < 0) break;
+            }
+            mn = mk3(px ? a.x : -b.x, py ? a.y : -b.y, pz ? a.z : -b.z);
+            mx = mk3(px ? b.x : -a.x, py ? b.y : -a.y, pz ? b.z : -a.z);
+#ifdef MI355RT_EXP_FASTONLY      // timing experiment (wrong results): what the walk costs when nothing ever leaves the fast descent
+            return;
+#endif
+        }
         if (info.x < 0) {
             // ---- leaf (reached => not skippable): what does intersect_leaf_triangles + contains give?
             const uint32_t tri_first = (uint32_t)~info.x, tri_count = (uint32_t)info.y;
@@ -428,23 +468,11 @@ __device__ inline void confirm_walk(const DScene& sc, f3 o, f3 d, float& t, floa
             const bool sx[2] = { (d.x > 0.0f && hp.x > md.x) || (d.x < 0.0f && hp.x < mn.x), (d.x > 0.0f && hp.x > mx.x) || (d.x < 0.0f && hp.x < md.x) };
             const bool sy[2] = { (d.y > 0.0f && hp.y > md.y) || (d.y < 0.0f && hp.y < mn.y), (d.y > 0.0f && hp.y > mx.y) || (d.y < 0.0f && hp.y < md.y) };
             const bool sz[2] = { (d.z > 0.0f && hp.z > md.z) || (d.z < 0.0f && hp.z < mn.z), (d.z > 0.0f && hp.z > mx.z) || (d.z < 0.0f && hp.z < md.z) };
-            // Fast decision.  Per axis take the allowed half with the smaller entry value lo: the child c0 made of these
-            // halves has the smallest sort key of all candidates (the key is max3 of the per-axis values, and max is
-            // monotone), so no candidate sorts strictly before it.  Another candidate TIES with it exactly when, on some
-            // axis where both halves are allowed, the other half's lo does not exceed c0's key (then the stable sort's
-            // child-index order decides).  No tie, c0 passes the slab test, a ray without inf / NaN in its inverse direction, not
-            // resuming: c0 is the reference's next child.  Anything else: the general scan over all eight children below.
-            const int nx = sx[0] ? 1 : (sx[1] ? 0 : (lox[1] < lox[0] ? 1 : 0));
-            const int ny = sy[0] ? 1 : (sy[1] ? 0 : (loy[1] < loy[0] ? 1 : 0));
-            const int nz = sz[0] ? 1 : (sz[1] ? 0 : (loz[1] < loz[0] ? 1 : 0));
-            const float key0 = fmaxf(fmaxf(nx ? lox[1] : lox[0], ny ? loy[1] : loy[0]), nz ? loz[1] : loz[0]);
-            const float tmax0 = fminf(fminf(nx ? hix[1] : hix[0], ny ? hiy[1] : hiy[0]), nz ? hiz[1] : hiz[0]);
+            // General decision (a tie, a failing slab test, a node the point at t* has wholly passed, a resume after a None, an
+            // inf / NaN inverse direction): scan all eight children like the reference's sort would order them.
             const bool none_allowed = (sx[0] & sx[1]) | (sy[0] & sy[1]) | (sz[0] & sz[1]);       // the point at t* is past this whole cube
-            const bool tie = (!sx[0] & !sx[1] & ((nx ? lox[0] : lox[1]) <= key0)) | (!sy[0] & !sy[1] & ((ny ? loy[0] : loy[1]) <= key0))
-                           | (!sz[0] & !sz[1] & ((nz ? loz[0] : loz[1]) <= key0));
-            const bool fast = !resuming & !special & !none_allowed & !tie & (tmax0 >= key0) & (tmax0 > 0.0f);
-            int best = fast ? (nx | (ny << 1) | (nz << 2)) : -1;
-            if (!fast & !none_allowed) {
+            int best = -1;
+            if (!none_allowed) {
                 float best_t = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
