@@ -10,12 +10,11 @@ constexpr uint32_t kSampleMax = 65535;
 constexpr uint32_t kMaxRecursions = 3;
 constexpr uint32_t kMaxLevels = kMaxRecursions + 1;
 
-// Ray-queue record, 48 bytes = 3 x float4, stored as three planes (q0 of every record, then q1, then q2)
-// so that a wave's 64 consecutive records are 1 KiB contiguous per plane:
-//   q0 = (o.x, o.y, o.z, d.x)   q1 = (d.y, d.z, slot, meta)
-//   q2 = radiance ray: (pixel, sample#, -, -) as bits;  shadow ray: (L.r, L.g, L.b, -)
-// meta: bit 0 kind (0 radiance, 1 shadow) | level << 4 | node << 8 | light << 24
-constexpr uint32_t kRayRecordBytes = 48;
+// Ray-queue record, 32 bytes = 2 x float4, stored as two planes (q0 of every record, then q1) so that a wave's 64
+// consecutive records are 1 KiB contiguous per plane.  Layout of the two kinds: kernels.hip ("ray records").
+// (Round 1-2a: 48 bytes; the shadow ray's origin and direction are now rebuilt from the hit point by the kernel that
+// traces it, and (pixel, sample number) moved to a per-slot side array: profiles/r02_notes.md.)
+constexpr uint32_t kRayRecordBytes = 32;
 constexpr uint32_t kShards = 64;            // copies of every contended device word (work cursors, counters)
 constexpr uint32_t kMaxRounds = kMaxRecursions + 2;
 constexpr uint32_t kCullRects = 16;
@@ -63,7 +62,8 @@ struct DPass {
     // primary-sample enumeration: thread i -> s = i / npix, p = i % npix,
     // row = rows[row0 + p / width], x = p % width, pixel = row * width + x
     const uint32_t* rows;
-    size_t qstride;           // records per queue: a queue is three float4 planes q0[], q1[], q2[] (structure of arrays)
+    size_t qstride;           // records per queue: a queue is two float4 planes q0[], q1[] (structure of arrays; layout: kernels.hip)
+    uint2* slot_ps;           // per light-term slot: (pixel, sample number) of its sample
     uint32_t* hit_prim;       // per radiance record: triangle hit or 0xFFFFFFFF (the 16-byte hit record is written for hits only)
     uint32_t row0;
     uint32_t row_wrap;        // entries of the cyclic row list (50-row frames: rows[(row0 + i) % row_wrap]); 0xFFFFFFFF: no wrap

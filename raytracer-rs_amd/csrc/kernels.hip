@@ -209,12 +209,29 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
     return i < n_rad ? base + i : base + (ps.region - 1u - (i - n_rad));
 }
 
-// a shadow ray that hit nothing is not blocked: store the light term it carries
+// ---- ray records: two float4 planes q0[], q1[] per queue (32 B per ray) --------------------------------------------
+//   radiance ray: q0 = { o.xyz, d.x },    q1 = { d.y, d.z, light-term slot of its sample, level << 4 | tree node << 8 }
+//   shadow ray:   q0 = { hp.xyz, term },  q1 = { c.xyz, - }   hp: the shaded hit point, term: float index of its light
+//                 term in slot_L, c: the finished term (stored when the ray turns out unblocked).  The ray itself is
+//                 rebuilt from hp and the light by the kernel that traces it — the expressions of mod.rs:215, 224-225
+//                 in the order shade() evaluates them, so the floats are the ones the reference traces.
+// (pixel, sample number) of a sample — the reflection sampler's hash inputs — live in ps.slot_ps, per light-term slot.
+__device__ __forceinline__ void shadow_ray_of(const DScene& sc, const float4 q0, f3& o, f3& d)
+{
+    uint32_t li = 0u;
+    if (sc.nlights > 1u) li = (__float_as_uint(q0.w) / 3u) % sc.nlights;      // term = 3 * ((slot * nodes + node) * nlights + li)
+    const DLight lt = sc.lights[li];
+    const f3 hp = mk3(q0.x, q0.y, q0.z);
+    const f3 l = sub3(mk3(lt.px, lt.py, lt.pz), hp);                           // mod.rs:215
+    o = add3(hp, vscale(l, 0.01f)); d = l;                                      // mod.rs:224-225
+}
+
+// a shadow ray that is not blocked (it hit nothing, or nothing in (0.01, 1)): store the light term it carries
 __device__ __forceinline__ void store_unblocked(const DPass& ps, uint32_t r, const float4* __restrict__ in_q, float* __restrict__ slot_L)
 {
-    const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
-    float* dst = slot_L + __float_as_uint(r1.z);
-    dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+    const float4 q0 = in_q[r], q1 = in_q[ps.qstride + r];
+    float* dst = slot_L + __float_as_uint(q0.w);
+    dst[0] = q1.x; dst[1] = q1.y; dst[2] = q1.z;
 }
 
 // ---- trace: closest hit of every ray of a round --------------------------------------------------
@@ -293,14 +310,17 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     const uint32_t r = w_chunk * ps.region + (shadow ? ps.region - 1u - (i - w_nrad) : i);
                     const char* __restrict__ p0 = (const char*)in_q;
                     const char* __restrict__ p1 = (const char*)(in_q + ps.qstride);
-                    const float4 r0 = *(const float4*)(p0 + (r << 4)), r1 = *(const float4*)(p1 + (r << 4));
-                    o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+                    const float4 r0 = *(const float4*)(p0 + (r << 4));
+                    float4 r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (!(CONFIRM && shadow)) r1 = *(const float4*)(p1 + (r << 4));    // CONFIRM: a shadow ray's second plane is the confirm step's business
                     rec = r;
-                    if (!CONFIRM && shadow) {       // keep what the finish needs in registers: no load when the ray ends
-                        const char* __restrict__ p2 = (const char*)(in_q + 2 * ps.qstride);
-                        sh_L4 = *(const float4*)(p2 + (r << 4));
-                        rec = __float_as_uint(r1.z);           // float index of its light term in slot_L (shade kernel)
-                    }
+                    if (shadow) {
+                        shadow_ray_of(sc, r0, o, d);
+                        if (!CONFIRM) {                 // keep what the finish needs in registers: no load when the ray ends
+                            sh_L4 = r1;
+                            rec = __float_as_uint(r0.w);           // float index of its light term in slot_L (shade kernel)
+                        }
+                    } else { o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
                 }
                 ray_init(rs, o, d, shadow, sc.root);
                 if (!CONFIRM && shadow) { rs.t = sh_L4.x; rs.u = sh_L4.y; rs.v = sh_L4.z; }
@@ -399,8 +419,9 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
                 r = (size_t)chunk * ps.region + i;
             } else {
                 r = record_index(ps, chunk, i, n_rad);
-                const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
-                o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+                const float4 r0 = in_q[r];
+                if (i < n_rad) { const float4 r1 = in_q[ps.qstride + r]; o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
+                else shadow_ray_of(sc, r0, o, d);
             }
             float t, u, v; uint32_t prim;
             octree_intersect(sc, o, d, t, u, v, prim);
@@ -408,9 +429,7 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
                 ps.hit_prim[r] = prim;
                 if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
             } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {          // not blocked, mod.rs:226-232
-                const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
-                float* dst = slot_L + __float_as_uint(r1.z);
-                dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+                store_unblocked(ps, (uint32_t)r, in_q, slot_L);
             }
         }
     }
@@ -437,8 +456,9 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
         uint32_t pixel, sampleno;
         primary_sample(cam, ps, film_n, sample_index, pixel, sampleno, o, d);
     } else {
-        const float4 r0 = in_q[r], r1 = in_q[ps.qstride + r];
-        o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
+        const float4 r0 = in_q[r];
+        if (shadow) shadow_ray_of(sc, r0, o, d);
+        else { const float4 r1 = in_q[ps.qstride + r]; o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
     }
     const float4 h = hits[r];
     float t = h.x, u = h.y, v = h.z; uint32_t prim = __float_as_uint(h.w);
@@ -452,9 +472,7 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
             if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
         }
     } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {               // not blocked, mod.rs:226-232
-        const float4 r1 = in_q[ps.qstride + r], r2 = in_q[2 * ps.qstride + r];
-        float* dst = slot_L + __float_as_uint(r1.z);
-        dst[0] = r2.x; dst[1] = r2.y; dst[2] = r2.z;
+        store_unblocked(ps, r, in_q, slot_L);
     }
 }
 
@@ -598,11 +616,13 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                     slot = chunk * ps.chunk + j + (uint32_t)lane;       // == sample_slot[chunk * ps.chunk + i]
                     primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
                 } else {
-                    const float4 r0 = in_q[base + i], r1 = in_q[ps.qstride + base + i], r2 = in_q[2 * ps.qstride + base + i];
+                    const float4 r0 = in_q[base + i], r1 = in_q[ps.qstride + base + i];
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
                     slot = __float_as_uint(r1.z); node = (__float_as_uint(r1.w) >> 8) & 0xFFFFu;
-                    pixel = __float_as_uint(r2.x); sampleno = __float_as_uint(r2.y);
+                    const uint2 px = ps.slot_ps[slot];
+                    pixel = px.x; sampleno = px.y;
                 }
+                if (PRIMARY && level < ps.recursions) ps.slot_ps[slot] = make_uint2(pixel, sampleno);   // what the deeper levels hash with
                 hp = add3(o, sscale(h.x, d));                                          // mod.rs:212
                 const float4 nn = ((const float4*)sc.normals)[__float_as_uint(h.w)];   // calc_normal, mod.rs:198-205 (precomputed)
                 n = mk3(nn.x, nn.y, nn.z);
@@ -611,15 +631,14 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             // ---- shade() set-up per light, mod.rs:214-257; the shadow ray carries the finished term
             for (uint32_t li = 0; li < sc.nlights; ++li) {
                 bool want = false;
-                f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 1), c = mk3(0, 0, 0);
+                f3 c = mk3(0, 0, 0);
                 if (active) {
                     const DLight lt = sc.lights[li];
                     const f3 l = sub3(mk3(lt.px, lt.py, lt.pz), hp);                   // mod.rs:215
                     const f3 ln = normalized3(l);
                     const float ndl = dot3(n, ln);                                     // mod.rs:216
                     if (!(ndl < 0.0f)) {                                               // mod.rs:218
-                        want = true;
-                        so = add3(hp, vscale(l, 0.01f)); sd = l;                       // mod.rs:224-225
+                        want = true;                                                   // the shadow ray of mod.rs:224-225: rebuilt from hp by its tracer (shadow_ray_of)
                         const DMaterial m = sc.materials[geom];
                         f3 diffuse = mk3(m.r, m.g, m.b);
                         if (m.kind_tex & 0x80000000u) diffuse = fetch_texel(sc, m.kind_tex & 0x7FFFFFFFu, h.y, h.z);
@@ -633,10 +652,9 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                 const uint32_t oi = wave_append(want, out_back, n_new);
                 if (want && out_front + oi < ps.region) {
                     const size_t r = base + (ps.region - 1u - oi);
-                    out_q[r] = make_float4(so.x, so.y, so.z, sd.x);
                     const uint32_t term = 3u * ((slot * ps.nodes_per_sample + node) * sc.nlights + li);    // float index in slot_L (< 2^32: renderer.cpp)
-                    out_q[ps.qstride + r] = make_float4(sd.y, sd.z, __uint_as_float(term), 0.0f);
-                    out_q[2 * ps.qstride + r] = make_float4(c.x, c.y, c.z, 0.0f);
+                    out_q[r] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(term));
+                    out_q[ps.qstride + r] = make_float4(c.x, c.y, c.z, 0.0f);
                 }
             }
             // ---- reflection rays, mod.rs:146-158 + 178-196
@@ -680,7 +698,6 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                         const size_t r = base + oi;
                         out_q[r] = make_float4(bo.x, bo.y, bo.z, bd.x);
                         out_q[ps.qstride + r] = make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8)));
-                        out_q[2 * ps.qstride + r] = make_float4(__uint_as_float(pixel), __uint_as_float(sampleno), 0.0f, 0.0f);
                     }
                 }
             }

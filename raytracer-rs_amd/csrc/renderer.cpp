@@ -403,6 +403,7 @@ void Renderer::free_pass_buffers()
         }
         if (sl.d_slot_L) { (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; }
         if (sl.d_sample_slot) { (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr; }
+        if (sl.d_slot_ps) { (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr; }
         if (sl.d_hits) { (void)hipFree(sl.d_hits); sl.d_hits = nullptr; }
         if (sl.d_hit_prim) { (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr; }
         sl.capacity = 0;
@@ -417,6 +418,7 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
     if (sl.capacity) {          // grow: release this slice's buffers only
         for (int i = 0; i < 2; ++i) { (void)hipFree(sl.d_queue[i]); sl.d_queue[i] = nullptr; (void)hipFree(sl.d_chunk_counts[i]); sl.d_chunk_counts[i] = nullptr; }
         (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr;
+        (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr;
         (void)hipFree(sl.d_hits); sl.d_hits = nullptr; (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr;
         sl.capacity = 0;
     }
@@ -434,6 +436,7 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
     HIP_ALLOC(hipMalloc((void**)&sl.d_hit_prim, records * 4));
     HIP_ALLOC(hipMalloc((void**)&sl.d_slot_L, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
     HIP_ALLOC(hipMalloc((void**)&sl.d_sample_slot, nchunks * chunk_ * 4));
+    HIP_ALLOC(hipMalloc((void**)&sl.d_slot_ps, nchunks * chunk_ * 8));
     sl.capacity = nsamples;
     sl.queue_records = records;
     return true;
@@ -465,7 +468,7 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
     ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
     ps.chunk = chunk; ps.nchunks = (uint32_t)((nsamples + chunk - 1) / chunk); ps.region = chunk * records_per_sample_;
-    ps.hit_prim = sl.d_hit_prim; ps.qstride = sl.queue_records;
+    ps.hit_prim = sl.d_hit_prim; ps.qstride = sl.queue_records; ps.slot_ps = (uint2*)sl.d_slot_ps;
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
     ps.refill_threshold = 24; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
@@ -685,7 +688,7 @@ bool Renderer::render(uint32_t spp)
         if (!assign_slice_rows(nsl)) return false;
         size_t target = (size_t)48 << 20;                               // samples per pass of one slice
         if (const char* e = getenv("MI355RT_PASS_SAMPLES")) { long v = atol(e); if (v >= 1024) target = (size_t)v; }
-        // The pass buffers (two ray queues, hit records, light terms: ~530 B per sample) are sized for the
+        // The pass buffers (two ray queues, hit records, light terms: ~410 B per sample) are sized for the
         // largest pass.  If the device cannot hold them (another tenant, a 16 GB part), halve the pass and
         // try again; results do not depend on how samples are batched into passes.
         struct PassDesc { uint32_t r0, nr, kk; };

@@ -87,6 +87,7 @@ private:
         void* d_hits = nullptr;
         uint32_t* d_hit_prim = nullptr;          // hit records of the round being processed (16 B per queue record)
         float* d_slot_L = nullptr;
+        void* d_slot_ps = nullptr;               // light-term slot -> (pixel, sample number) of its sample (uint2)
         uint32_t* d_sample_slot = nullptr;       // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
         size_t capacity = 0;                     // samples
         size_t queue_records = 0;
