@@ -20,6 +20,7 @@ constexpr uint32_t kMaxRounds = kMaxRecursions + 2;
 constexpr uint32_t kCullRects = 16;
 constexpr uint32_t kMaxCursors = 64;
 constexpr uint32_t kCtrlWordsPerRound = kMaxCursors * 16384;   // work cursors of one round, 64 KiB apart
+constexpr uint32_t kShadeCursorOffset = 128;                   // the shade launch of a round: 512 B after
 constexpr uint32_t kConfirmCursorOffset = 64;                  // the confirm launch of a round: its cursors sit 256 B after the trace launch's
 
 struct DMaterial { float r, g, b; uint32_t kind_tex; };       // kind_tex: bit 31 = texture, low bits = texture id

@@ -44,6 +44,16 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 #ifndef MI355RT_CONFIRM_BLOCKS
 #define MI355RT_CONFIRM_BLOCKS 5               // blocks per CU the confirm kernel is compiled for (A/B knob, profiles/r02_notes.md)
 #endif
+#ifndef MI355RT_SHADE_P_BLOCKS
+#define MI355RT_SHADE_P_BLOCKS 5               // blocks per CU the shade kernels are compiled for and launched with (A/B knobs)
+#endif
+#ifndef MI355RT_SHADE_S_BLOCKS
+#define MI355RT_SHADE_S_BLOCKS 8
+#endif
+#ifndef MI355RT_SHADE_PULL
+#define MI355RT_SHADE_PULL 0                   // 0: like the trace kernel (ps.pull_mode); 2: static striding
+#endif
+constexpr uint32_t kShadePullMode = MI355RT_SHADE_PULL;
 #ifndef MI355RT_CONFIRM_PULL
 #define MI355RT_CONFIRM_PULL 0                 // 0: like the trace kernel (ps.pull_mode); 2: static striding (A/B knob)
 #endif
@@ -96,6 +106,33 @@ __device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, u
     if (lane_id() == 0) v = atomicAdd(cursor, 1u);
     chunk = bcast_first(v);
     return chunk < nchunks;
+}
+
+// Streamed data (ray records, hit records, slot bookkeeping: written once, read once, gigabytes per pass) can be marked
+// non-temporal so that it does not evict the BVH from the L2.  MI355RT_NT is a build knob (bit 0: ray-record loads of the
+// trace kernel, 1: its hit stores, 2: the shade kernel's streams, 3: the confirm kernel's loads); see profiles/r02_notes.md.
+#ifndef MI355RT_NT
+#define MI355RT_NT 4
+#endif
+constexpr uint32_t kNT = MI355RT_NT;
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <uint32_t BIT> __device__ __forceinline__ float4 ld4(const float4* p)
+{
+    if constexpr ((kNT >> BIT) & 1u) { const v4f_t v = __builtin_nontemporal_load((const v4f_t*)p); return make_float4(v.x, v.y, v.z, v.w); }
+    else return *p;
+}
+template <uint32_t BIT> __device__ __forceinline__ void st4(float4* p, float4 a)
+{
+    if constexpr ((kNT >> BIT) & 1u) { v4f_t v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; __builtin_nontemporal_store(v, (v4f_t*)p); }
+    else *p = a;
+}
+template <uint32_t BIT> __device__ __forceinline__ uint32_t ld1(const uint32_t* p)
+{
+    if constexpr ((kNT >> BIT) & 1u) return __builtin_nontemporal_load(p); else return *p;
+}
+template <uint32_t BIT> __device__ __forceinline__ void st1(uint32_t* p, uint32_t a)
+{
+    if constexpr ((kNT >> BIT) & 1u) __builtin_nontemporal_store(a, p); else *p = a;
 }
 
 // wave64 compaction: every lane of the wave calls this; lanes with want == true get consecutive
@@ -310,9 +347,9 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     const uint32_t r = w_chunk * ps.region + (shadow ? ps.region - 1u - (i - w_nrad) : i);
                     const char* __restrict__ p0 = (const char*)in_q;
                     const char* __restrict__ p1 = (const char*)(in_q + ps.qstride);
-                    const float4 r0 = *(const float4*)(p0 + (r << 4));
+                    const float4 r0 = ld4<0>((const float4*)(p0 + (r << 4)));
                     float4 r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (!(CONFIRM && shadow)) r1 = *(const float4*)(p1 + (r << 4));    // CONFIRM: a shadow ray's second plane is the confirm step's business
+                    if (!(CONFIRM && shadow)) r1 = ld4<0>((const float4*)(p1 + (r << 4)));    // CONFIRM: a shadow ray's second plane is the confirm step's business
                     rec = r;
                     if (shadow) {
                         shadow_ray_of(sc, r0, o, d);
@@ -356,15 +393,15 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     if (hit) hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]),
                                                  add3(rs.o, vscale(rs.d, rs.t)));
                     if (rs.occ < 0) {                                           // radiance ray
-                        *(uint32_t*)((char*)ps.hit_prim + (rec << 2)) = hit ? rs.prim : kMiss;
-                        if (hit) *(float4*)((char*)hits + (rec << 4)) = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
+                        st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), hit ? rs.prim : kMiss);
+                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
                     } else if (!(hit && rs.t > 0.01f && rs.t < 1.0f)) {          // shadow ray, not blocked (mod.rs:226-232)
                         store_unblocked(ps, rec, in_q, slot_L);
                     }
                 } else
                 if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
-                    *(uint32_t*)((char*)ps.hit_prim + (rec << 2)) = rs.prim;     // 4 B for every ray, the 16 B record only for hits
-                    if (rs.prim != kMiss) *(float4*)((char*)hits + (rec << 4)) = make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim));
+                    st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), rs.prim);     // 4 B for every ray, the 16 B record only for hits
+                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
                 } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
                     float* dst = slot_L + rec;
                     dst[0] = rs.t; dst[1] = rs.u; dst[2] = rs.v;
@@ -456,11 +493,11 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
         uint32_t pixel, sampleno;
         primary_sample(cam, ps, film_n, sample_index, pixel, sampleno, o, d);
     } else {
-        const float4 r0 = in_q[r];
+        const float4 r0 = ld4<3>(&in_q[r]);
         if (shadow) shadow_ray_of(sc, r0, o, d);
-        else { const float4 r1 = in_q[ps.qstride + r]; o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
+        else { const float4 r1 = ld4<3>(&in_q[ps.qstride + r]); o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
     }
-    const float4 h = hits[r];
+    const float4 h = ld4<3>(&hits[r]);
     float t = h.x, u = h.y, v = h.z; uint32_t prim = __float_as_uint(h.w);
     const uint32_t prim_in = prim;
 #ifndef MI355RT_EXP_NOWALK          // timing experiment (wrong results): the confirm kernel's gathers and stores without the walk
@@ -493,7 +530,7 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
         const uint32_t i = it + (uint32_t)lane;
         const bool valid = i < n_tot;
         const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
-        const bool hit = valid && ps.hit_prim[r] != kMiss;
+        const bool hit = valid && ld1<3>(&ps.hit_prim[r]) != kMiss;
         if (!PRIMARY && valid && !hit && i >= n_rad) store_unblocked(ps, r, in_q, slot_L);
         uint32_t n_new;
         const uint32_t pos = wave_append(hit, cnt, n_new);
@@ -533,7 +570,7 @@ __global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel
             const uint32_t i = it + (uint32_t)lane;
             const bool valid = i < n_tot;
             const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
-            const bool hit = valid && ps.hit_prim[r] != kMiss;
+            const bool hit = valid && ld1<3>(&ps.hit_prim[r]) != kMiss;
             if (!PRIMARY && valid && !hit && i >= n_rad) store_unblocked(ps, r, in_q, slot_L);
             uint32_t n_new;
             const uint32_t pos = wave_append(hit, cnt, n_new);
@@ -580,13 +617,13 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
         uint32_t cnt = 0u;
         for (uint32_t it = 0; it < n_rad; it += 64u) {
             const uint32_t i = it + (uint32_t)lane;
-            const bool valid = i < n_rad && ps.hit_prim[base + i] != kMiss;
+            const bool valid = i < n_rad && ld1<2>(&ps.hit_prim[base + i]) != kMiss;
             uint32_t n_new;
             const uint32_t pos = wave_append(valid, cnt, n_new);
             if (valid) list[pos] = i;
             // primary round: light-term slots are handed out per chunk to the samples that hit something
             // (74 % of the primary samples miss and need neither a slot nor zero-filling)
-            if (PRIMARY && i < n_rad) sample_slot[chunk * ps.chunk + i] = valid ? chunk * ps.chunk + pos : kMiss;
+            if (PRIMARY && i < n_rad) st1<2>(&sample_slot[chunk * ps.chunk + i], valid ? chunk * ps.chunk + pos : kMiss);
         }
         if (PRIMARY) {
             // zero the slots this chunk uses: a node whose shadow ray is blocked, or that is never
@@ -596,7 +633,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             const uint32_t total = cnt * per;
             if ((((size_t)chunk * ps.chunk * per) & 3u) == 0u) {               // 16-byte aligned chunk base: wide stores
                 float4* z4 = (float4*)z;
-                for (uint32_t k = (uint32_t)lane; k < total / 4u; k += 64u) z4[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (uint32_t k = (uint32_t)lane; k < total / 4u; k += 64u) st4<2>(&z4[k], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 for (uint32_t k = (total & ~3u) + (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
             } else {
                 for (uint32_t k = (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
@@ -611,12 +648,12 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             float4 h = make_float4(0, 0, 0, 0);
             if (active) {
                 const uint32_t i = list[j + (uint32_t)lane];
-                h = hits[base + i];
+                h = ld4<2>(&hits[base + i]);
                 if (PRIMARY) {
                     slot = chunk * ps.chunk + j + (uint32_t)lane;       // == sample_slot[chunk * ps.chunk + i]
                     primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
                 } else {
-                    const float4 r0 = in_q[base + i], r1 = in_q[ps.qstride + base + i];
+                    const float4 r0 = ld4<2>(&in_q[base + i]), r1 = ld4<2>(&in_q[ps.qstride + base + i]);
                     o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y);
                     slot = __float_as_uint(r1.z); node = (__float_as_uint(r1.w) >> 8) & 0xFFFFu;
                     const uint2 px = ps.slot_ps[slot];
@@ -653,8 +690,8 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                 if (want && out_front + oi < ps.region) {
                     const size_t r = base + (ps.region - 1u - oi);
                     const uint32_t term = 3u * ((slot * ps.nodes_per_sample + node) * sc.nlights + li);    // float index in slot_L (< 2^32: renderer.cpp)
-                    out_q[r] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(term));
-                    out_q[ps.qstride + r] = make_float4(c.x, c.y, c.z, 0.0f);
+                    st4<2>(&out_q[r], make_float4(hp.x, hp.y, hp.z, __uint_as_float(term)));
+                    st4<2>(&out_q[ps.qstride + r], make_float4(c.x, c.y, c.z, 0.0f));
                 }
             }
             // ---- reflection rays, mod.rs:146-158 + 178-196
@@ -696,8 +733,8 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                     const uint32_t oi = wave_append(active, out_front, n_new);
                     if (active && oi + out_back < ps.region + 0u) {
                         const size_t r = base + oi;
-                        out_q[r] = make_float4(bo.x, bo.y, bo.z, bd.x);
-                        out_q[ps.qstride + r] = make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8)));
+                        st4<2>(&out_q[r], make_float4(bo.x, bo.y, bo.z, bd.x));
+                        st4<2>(&out_q[ps.qstride + r], make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8))));
                     }
                 }
             }
@@ -722,18 +759,20 @@ __device__ __forceinline__ void flush_shade_counters(DCounters* counters, uint32
 }
 
 template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock, PRIMARY ? 5 : 7) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
+__global__ __launch_bounds__(kBlock, PRIMARY ? MI355RT_SHADE_P_BLOCKS : MI355RT_SHADE_S_BLOCKS) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       const float4* __restrict__ hits,
-                                                      float4* __restrict__ out_q, uint2* __restrict__ out_counts,
+                                                      float4* __restrict__ out_q, uint2* __restrict__ out_counts, uint32_t* cursor,
                                                       float* __restrict__ slot_L, uint32_t* __restrict__ sample_slot,
                                                       const uint32_t* __restrict__ film_n, DCounters* counters)
 {
     extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.list_cap hit indices
     const LinearList list{ &s_list[(threadIdx.x >> 6) * ps.list_cap] };
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
-    for (uint32_t chunk = wave; chunk < ps.nchunks; chunk += nwaves) {
+    // chunks are pulled from the round's cursors: the hits sit in a part of the image, culled / empty chunks cost nothing
+    PullState pull; uint32_t chunk = 0u;
+    while (pull_chunk(cursor, ps.nchunks, kShadePullMode ? kShadePullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
         uint32_t o_rad, o_sh;
         shade_chunk<PRIMARY>(sc, cam, ps, level, chunk, list, in_q, PRIMARY ? 0u : in_counts[chunk].x, o_rad, o_sh, hits, out_q, out_counts, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
     }
@@ -1038,7 +1077,7 @@ static int trace_blocks_per_cu(size_t lds)
 }
 
 template <bool P, bool C, bool F>
-static hipError_t launch_trace_variant(hipStream_t stream, int num_cus, const DScene& sc, const DCamera& cam, const DPass& ps,
+static hipError_t launch_trace_variant(hipStream_t stream, int num_cus, int blocks_per_cu_cap, const DScene& sc, const DCamera& cam, const DPass& ps,
                                        const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
                                        float* slot_L, const uint32_t* film_n, DCounters* counters)
 {
@@ -1046,6 +1085,7 @@ static hipError_t launch_trace_variant(hipStream_t stream, int num_cus, const DS
     const size_t lds = stack_bytes(ps.stack_depth);
     const int per_cu = trace_blocks_per_cu<P, C, F>(lds);
     int use_per_cu = per_cu;
+    if (blocks_per_cu_cap > 0 && blocks_per_cu_cap < use_per_cu) use_per_cu = blocks_per_cu_cap;      // leave room for another stream's kernels
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= per_cu) use_per_cu = v; }   // occupancy experiment
     hipLaunchKernelGGL((trace_kernel<P, C, F>), dim3((unsigned)(num_cus * use_per_cu)), dim3(kBlock), lds, stream, sc, cam, ps,
                        (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n, counters);
@@ -1053,11 +1093,11 @@ static hipError_t launch_trace_variant(hipStream_t stream, int num_cus, const DS
 }
 
 // confirm: the octree confirm step follows (reference-default semantics); primary rays are radiance rays either way
-hipError_t launch_trace(hipStream_t stream, int num_cus, bool primary, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
+hipError_t launch_trace(hipStream_t stream, int num_cus, int blocks_per_cu_cap, bool primary, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
                         const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
                         float* slot_L, const uint32_t* film_n, DCounters* counters)
 {
-#define MI355RT_TRACE_ARGS stream, num_cus, sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters
+#define MI355RT_TRACE_ARGS stream, num_cus, blocks_per_cu_cap, sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters
     if (primary) return count ? launch_trace_variant<true, true, true>(MI355RT_TRACE_ARGS) : launch_trace_variant<true, false, true>(MI355RT_TRACE_ARGS);
     if (confirm) return count ? launch_trace_variant<false, true, true>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, true>(MI355RT_TRACE_ARGS);
     return count ? launch_trace_variant<false, true, false>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, false>(MI355RT_TRACE_ARGS);
@@ -1078,19 +1118,19 @@ hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, co
 }
 
 hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
-                        const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts,
+                        const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts, uint32_t* cursor,
                         float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters)
 {
     const size_t lds = (size_t)ps.list_cap * kWavesPerBlock * sizeof(uint32_t);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned cap = (unsigned)num_cus * 8u;
+    const unsigned cap = (unsigned)num_cus * (primary ? MI355RT_SHADE_P_BLOCKS : MI355RT_SHADE_S_BLOCKS);    // what the chip holds at once
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(kBlock);
     if (primary) hipLaunchKernelGGL((shade_kernel<true>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
-                                    (const float4*)hits, (float4*)out_q, (uint2*)out_counts, slot_L, sample_slot, film_n, counters);
+                                    (const float4*)hits, (float4*)out_q, (uint2*)out_counts, cursor, slot_L, sample_slot, film_n, counters);
     else hipLaunchKernelGGL((shade_kernel<false>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
-                            (const float4*)hits, (float4*)out_q, (uint2*)out_counts, slot_L, sample_slot, film_n, counters);
+                            (const float4*)hits, (float4*)out_q, (uint2*)out_counts, cursor, slot_L, sample_slot, film_n, counters);
     return hipGetLastError();
 }
 

@@ -252,9 +252,11 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_tmp_rows_, nullptr, 64 * 4)) return bail();
     if (!upload(d_counters_, nullptr, sizeof(DCounters) * kShards)) return bail();
     slices_[0].stream = stream_;
+    if (hipStreamCreateWithFlags(&trace_stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
     for (uint32_t i = 0; i < kMaxSlices; ++i) {
         if (i && hipStreamCreateWithFlags(&slices_[i].stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
-        if (hipEventCreateWithFlags(&slices_[i].done, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
+        if (hipEventCreateWithFlags(&slices_[i].done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&slices_[i].ev_ready, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&slices_[i].ev_traced, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
         if (!upload(slices_[i].d_ctrl, nullptr, kMaxRounds * kCtrlWordsPerRound * 4)) return bail();
         if (!upload(slices_[i].d_rows, nullptr, (size_t)cfg.height * 4)) return bail();
     }
@@ -284,7 +286,10 @@ Renderer::~Renderer()
     for (uint32_t i = 0; i < kMaxSlices; ++i) {
         if (i && slices_[i].stream) { (void)hipStreamSynchronize(slices_[i].stream); (void)hipStreamDestroy(slices_[i].stream); }
         if (slices_[i].done) (void)hipEventDestroy(slices_[i].done);
+        if (slices_[i].ev_ready) (void)hipEventDestroy(slices_[i].ev_ready);
+        if (slices_[i].ev_traced) (void)hipEventDestroy(slices_[i].ev_traced);
     }
+    if (trace_stream_) { (void)hipStreamSynchronize(trace_stream_); (void)hipStreamDestroy(trace_stream_); }
     for (void* p : allocs_) (void)hipFree(p);
     if (h_ldr_) (void)hipHostFree(h_ldr_);
     comm_destroy();
@@ -478,59 +483,89 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     ps.ncursors = 64; if (const char* e = getenv("MI355RT_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxCursors) ps.ncursors = (uint32_t)v; }
 }
 
-bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample, uint32_t row_wrap)
+// A wavefront pass in three steps, so that a frame can interleave the rounds of its slices (render()):
+// pass_begin: buffers, descriptor, cursors; pass_round(r): trace (+ confirm) (+ shade) of round r; pass_end: resolve.
+// The trace launch of a round goes to `trace_stream` when one is given — ordered after the slice's own stream and before
+// what the slice queues next — everything else to the slice's stream.
+bool Renderer::pass_begin(PassRun& run, Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample, uint32_t row_wrap)
 {
+    run.sl = &sl; run.live = false;
     const uint32_t npix = explicit_sample ? 1u : nrows * cfg.width;
     const size_t nsamples = (size_t)npix * spp;
     if (nsamples == 0) return true;
     if (!ensure_pass_capacity(sl, nsamples)) return false;
-    hipStream_t st = sl.stream;             // every launch of this pass goes to the slice's stream
-    DPass ps;
-    describe_pass(ps, sl, d_rows, row0, row_wrap, npix, nsamples, chunk_, explicit_sample, epixel, esample);
-    const DCamera cam = device_camera();
+    describe_pass(run.ps, sl, d_rows, row0, row_wrap, npix, nsamples, chunk_, explicit_sample, epixel, esample);
+    run.cam = device_camera();
+    run.rounds = cfg.recursions + 2;
+    HIP_TRY(hipMemsetAsync(sl.d_ctrl, 0, kMaxRounds * kCtrlWordsPerRound * 4, sl.stream));
+    run.live = true;
+    return true;
+}
+
+// round r: trace the rays of level r (+ the shadow rays emitted by level r-1), then shade level r
+bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, int trace_blocks_per_cu)
+{
+    if (!run.live || r >= run.rounds) return true;
+    Slice& sl = *run.sl;
+    const DPass& ps = run.ps;
+    const DCamera& cam = run.cam;
+    hipStream_t st = sl.stream;             // confirm / shade launches of this pass go to the slice's stream
+    hipStream_t tst = trace_stream ? trace_stream : st;
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
     const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
-
-    HIP_TRY(hipMemsetAsync(sl.d_ctrl, 0, kMaxRounds * kCtrlWordsPerRound * 4, st));
-    // round r: trace the rays of level r (+ the shadow rays emitted by level r-1), then shade level r
-    const uint32_t rounds = cfg.recursions + 2;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        if (timed) {
-            if (ev_used_ + 2 > ev_pool_.size()) {
-                for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); ev_pool_.push_back(ev); }
-            }
-            HIP_TRY(hipEventRecord(ev_pool_[ev_used_], st));
+    if (tst != st) { HIP_TRY(hipEventRecord(sl.ev_ready, st)); HIP_TRY(hipStreamWaitEvent(tst, sl.ev_ready, 0)); }
+    if (timed) {
+        if (ev_used_ + 2 > ev_pool_.size()) {
+            for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); ev_pool_.push_back(ev); }
         }
-        const void* in_q = r == 0 ? nullptr : sl.d_queue[(r - 1) & 1];
-        const void* in_c = r == 0 ? nullptr : sl.d_chunk_counts[(r - 1) & 1];
-        const bool balance_dbg = count && getenv("MI355RT_DEBUG_UTIL") && mode_ != kModeOctreeWalk;
-        if (balance_dbg) {       // load-balance diagnostics of this launch (debug only: synchronises)
-            DCounters init{};
-            HIP_TRY(hipMemcpy(&init, d_counters_, sizeof init, hipMemcpyDeviceToHost));
-            init.t_first_end = ~0ull; init.t_start = ~0ull; init.t_last_end = 0; init.t_sum_end = 0; init.n_waves = 0;
-            HIP_TRY(hipMemcpy(d_counters_, &init, sizeof init, hipMemcpyHostToDevice));
-        }
-        if (mode_ == kModeOctreeWalk)
-            HIP_TRY(launch_trace_octree(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
-        else
-            HIP_TRY(launch_trace(st, num_cus_, r == 0, count, mode_ == kModeConfirm, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
-        if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], st)); ev_used_ += 2; }
-        ++launches_;
-        if (mode_ == kModeConfirm && !dscene_.oct_single_leaf)   // true closest hits -> the reference intersector's answers; settles the shadow rays of this round (one-leaf octrees: done in the trace kernel)
-            HIP_TRY(launch_confirm(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound + kConfirmCursorOffset, sl.d_slot_L, d_film_n_));
-        if (balance_dbg) {
-            DCounters c0{};
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipMemcpy(&c0, d_counters_, sizeof c0, hipMemcpyDeviceToHost));
-            if (c0.n_waves)
-                fprintf(stderr, "[mi355rt] trace round %u: %llu waves, mean wave busy %.1f us, first wave out of work at %.1f us, last at %.1f us\n", r, c0.n_waves,
-                        (double)c0.t_sum_end / c0.n_waves / 100.0, (double)(c0.t_first_end - c0.t_start) / 100.0, (double)(c0.t_last_end - c0.t_start) / 100.0);
-        }
-        if (r <= cfg.recursions)
-            HIP_TRY(launch_shade(st, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, sl.d_hits, sl.d_queue[r & 1], sl.d_chunk_counts[r & 1], sl.d_slot_L, sl.d_sample_slot, d_film_n_, d_counters_));
+        HIP_TRY(hipEventRecord(ev_pool_[ev_used_], tst));
     }
-    HIP_TRY(launch_resolve(st, ps, cfg.width, nlights_, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
+    const void* in_q = r == 0 ? nullptr : sl.d_queue[(r - 1) & 1];
+    const void* in_c = r == 0 ? nullptr : sl.d_chunk_counts[(r - 1) & 1];
+    const bool balance_dbg = count && getenv("MI355RT_DEBUG_UTIL") && mode_ != kModeOctreeWalk;
+    if (balance_dbg) {       // load-balance diagnostics of this launch (debug only: synchronises)
+        DCounters init{};
+        HIP_TRY(hipMemcpy(&init, d_counters_, sizeof init, hipMemcpyDeviceToHost));
+        init.t_first_end = ~0ull; init.t_start = ~0ull; init.t_last_end = 0; init.t_sum_end = 0; init.n_waves = 0;
+        HIP_TRY(hipMemcpy(d_counters_, &init, sizeof init, hipMemcpyHostToDevice));
+    }
+    if (mode_ == kModeOctreeWalk)
+        HIP_TRY(launch_trace_octree(tst, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
+    else
+        HIP_TRY(launch_trace(tst, num_cus_, trace_blocks_per_cu, r == 0, count, mode_ == kModeConfirm, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
+    if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], tst)); ev_used_ += 2; }
+    ++launches_;
+    if (tst != st) { HIP_TRY(hipEventRecord(sl.ev_traced, tst)); HIP_TRY(hipStreamWaitEvent(st, sl.ev_traced, 0)); }
+    if (mode_ == kModeConfirm && !dscene_.oct_single_leaf)   // true closest hits -> the reference intersector's answers; settles the shadow rays of this round (one-leaf octrees: done in the trace kernel)
+        HIP_TRY(launch_confirm(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound + kConfirmCursorOffset, sl.d_slot_L, d_film_n_));
+    if (balance_dbg) {
+        DCounters c0{};
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(&c0, d_counters_, sizeof c0, hipMemcpyDeviceToHost));
+        if (c0.n_waves)
+            fprintf(stderr, "[mi355rt] trace round %u: %llu waves, mean wave busy %.1f us, first wave out of work at %.1f us, last at %.1f us\n", r, c0.n_waves,
+                    (double)c0.t_sum_end / c0.n_waves / 100.0, (double)(c0.t_first_end - c0.t_start) / 100.0, (double)(c0.t_last_end - c0.t_start) / 100.0);
+    }
+    if (r <= cfg.recursions)
+        HIP_TRY(launch_shade(st, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, sl.d_hits, sl.d_queue[r & 1], sl.d_chunk_counts[r & 1], sl.d_ctrl + r * kCtrlWordsPerRound + kShadeCursorOffset, sl.d_slot_L, sl.d_sample_slot, d_film_n_, d_counters_));
     return true;
+}
+
+bool Renderer::pass_end(PassRun& run)
+{
+    if (!run.live) return true;
+    Slice& sl = *run.sl;
+    HIP_TRY(launch_resolve(sl.stream, run.ps, cfg.width, nlights_, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
+    run.live = false;
+    return true;
+}
+
+bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample, uint32_t row_wrap)
+{
+    PassRun run;
+    if (!pass_begin(run, sl, d_rows, row0, nrows, spp, explicit_sample, epixel, esample, row_wrap)) return false;
+    for (uint32_t r = 0; r < run.rounds; ++r) if (!pass_round(run, r, nullptr, 0)) return false;
+    return pass_end(run);
 }
 
 bool Renderer::begin_call()
@@ -718,16 +753,33 @@ bool Renderer::render(uint32_t spp)
         // fork: the other slices start after everything already queued on the main stream
         for (uint32_t s = 1; s < nsl; ++s) HIP_TRY(hipStreamWaitEvent(slices_[s].stream, ev_begin_, 0));
         active_slices_ = nsl;
-        // enqueue the passes round-robin so that no stream waits for the host
+        // Enqueue the passes round-robin so that no stream waits for the host: every slice's whole pass on its own stream.
+        // Measured alternative (MI355RT_PIPELINE=1, profiles/r02_notes.md): all trace launches on ONE stream, round by round,
+        // so that a slice's confirm / shade / resolve launches (memory latency) run beside the NEXT slice's trace (VALU issue).
+        // The schedule comes out as planned, but a trace kernel with a streaming kernel beside it runs 20-25 % longer and the
+        // frame loses 2 ms against the slices left to themselves (which fall into lockstep: 3 traces, then 3 shades).
+        const bool pipelined = nsl > 1 && getenv("MI355RT_PIPELINE");
+        int tcap = 0;
+        if (const char* e = getenv("MI355RT_PIPE_BLOCKS")) { int v = atoi(e); if (v >= 0) tcap = v; }
+        if (pipelined) HIP_TRY(hipStreamWaitEvent(trace_stream_, ev_begin_, 0));
         for (size_t p = 0;; ++p) {
             bool any = false;
+            PassRun run[kMaxSlices];
+            uint32_t rounds = 0;
             for (uint32_t s = 0; s < nsl; ++s) {
                 if (p >= plan[s].size()) continue;
                 any = true;
                 const PassDesc& d = plan[s][p];
-                if (!run_pass(slices_[s], slices_[s].d_rows, d.r0, d.nr, d.kk, false, 0, 0)) return false;
+                if (!pipelined) { if (!run_pass(slices_[s], slices_[s].d_rows, d.r0, d.nr, d.kk, false, 0, 0)) return false; continue; }
+                if (!pass_begin(run[s], slices_[s], slices_[s].d_rows, d.r0, d.nr, d.kk, false, 0, 0, 0xFFFFFFFFu)) return false;
+                rounds = std::max(rounds, run[s].rounds);
             }
             if (!any) break;
+            if (!pipelined) continue;
+            for (uint32_t r = 0; r < rounds; ++r)
+                for (uint32_t s = 0; s < nsl; ++s)
+                    if (!pass_round(run[s], r, trace_stream_, tcap)) return false;
+            for (uint32_t s = 0; s < nsl; ++s) if (!pass_end(run[s])) return false;
         }
     }
     for (uint32_t r : owned_rows) ldr_dirty_[r] = 1;

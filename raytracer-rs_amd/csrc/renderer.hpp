@@ -79,6 +79,7 @@ private:
     struct Slice {
         hipStream_t stream = nullptr;            // slice 0 runs on the renderer's main stream
         hipEvent_t done = nullptr;
+        hipEvent_t ev_ready = nullptr, ev_traced = nullptr;   // slice stream -> trace stream -> slice stream, per round (render())
         std::vector<uint32_t> rows;              // this slice's rows (host copy of d_rows)
         uint32_t* d_rows = nullptr;
         uint32_t* d_ctrl = nullptr;              // per round: chunk cursors
@@ -95,6 +96,10 @@ private:
     bool ensure_pass_capacity(Slice& sl, size_t nsamples);
     void free_pass_buffers();
     bool assign_slice_rows(uint32_t nslices);
+    struct PassRun { Slice* sl = nullptr; DPass ps; DCamera cam; uint32_t rounds = 0; bool live = false; };
+    bool pass_begin(PassRun& run, Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample, uint32_t row_wrap);
+    bool pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, int trace_blocks_per_cu);
+    bool pass_end(PassRun& run);
     bool run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t nrows, uint32_t spp, bool explicit_sample, uint32_t epixel, uint32_t esample, uint32_t row_wrap = 0xFFFFFFFFu);
     void describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t row_wrap, uint32_t npix, size_t nsamples, uint32_t chunk,
                        bool explicit_sample, uint32_t epixel, uint32_t esample) const;
@@ -108,6 +113,7 @@ private:
     template <class T> bool upload(T*& dptr, const void* src, size_t bytes);
 
     int num_cus_ = 0;
+    hipStream_t trace_stream_ = nullptr;         // the trace launches of a multi-slice frame, round by round
     hipStream_t stream_ = nullptr;
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
     std::vector<hipEvent_t> ev_pool_;

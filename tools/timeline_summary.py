@@ -16,12 +16,12 @@ t0 = min(int(r["Start_Timestamp"]) for r in frame); t1 = max(int(r["End_Timestam
 print("frame kernels %d  span %.2f ms" % (len(frame), (t1 - t0) / 1e6))
 ev = []
 for r in frame:
-    k = "T" if "trace_kernel" in r["Kernel_Name"] else ("S" if "shade" in r["Kernel_Name"] else "R")
+    k = "T" if "trace_kernel" in r["Kernel_Name"] else ("S" if "shade" in r["Kernel_Name"] else ("C" if "confirm" in r["Kernel_Name"] else "R"))
     ev.append((int(r["Start_Timestamp"]), 1, k)); ev.append((int(r["End_Timestamp"]), -1, k))
 ev.sort()
-cnt = {"T": 0, "S": 0, "R": 0}; prev = t0; acc = {}
+cnt = {"T": 0, "S": 0, "C": 0, "R": 0}; prev = t0; acc = {}
 for t, dlt, k in ev:
-    key = "T%d S%d R%d" % (cnt["T"], cnt["S"], cnt["R"])
+    key = "T%d S%d C%d R%d" % (cnt["T"], cnt["S"], cnt["C"], cnt["R"])
     acc[key] = acc.get(key, 0) + (t - prev); prev = t
     cnt[k] += dlt
 for key, v in sorted(acc.items(), key=lambda x: -x[1])[:12]:
