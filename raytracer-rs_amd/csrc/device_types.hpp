@@ -74,6 +74,7 @@ struct DPass {
     uint32_t flags;
     uint32_t recursions, spread;
     uint32_t nodes_per_sample;
+    uint32_t nslots;          // light-term slots of the pass (nchunks * chunk): the stride between the planes of slot_L
     uint32_t level_first[kMaxLevels + 1];
     uint32_t use_explicit, explicit_pixel, explicit_sampleno;
     uint32_t chunk;           // primary samples per chunk

@@ -253,10 +253,10 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
 //                 rebuilt from hp and the light by the kernel that traces it — the expressions of mod.rs:215, 224-225
 //                 in the order shade() evaluates them, so the floats are the ones the reference traces.
 // (pixel, sample number) of a sample — the reflection sampler's hash inputs — live in ps.slot_ps, per light-term slot.
-__device__ __forceinline__ void shadow_ray_of(const DScene& sc, const float4 q0, f3& o, f3& d)
+__device__ __forceinline__ void shadow_ray_of(const DScene& sc, const DPass& ps, const float4 q0, f3& o, f3& d)
 {
     uint32_t li = 0u;
-    if (sc.nlights > 1u) li = (__float_as_uint(q0.w) / 3u) % sc.nlights;      // term = 3 * ((slot * nodes + node) * nlights + li)
+    if (sc.nlights > 1u) li = (__float_as_uint(q0.w) / 3u / ps.nslots) % sc.nlights;      // term = 3 * ((node * nlights + li) * nslots + slot)
     const DLight lt = sc.lights[li];
     const f3 hp = mk3(q0.x, q0.y, q0.z);
     const f3 l = sub3(mk3(lt.px, lt.py, lt.pz), hp);                           // mod.rs:215
@@ -352,7 +352,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     if (!(CONFIRM && shadow)) r1 = ld4<0>((const float4*)(p1 + (r << 4)));    // CONFIRM: a shadow ray's second plane is the confirm step's business
                     rec = r;
                     if (shadow) {
-                        shadow_ray_of(sc, r0, o, d);
+                        shadow_ray_of(sc, ps, r0, o, d);
                         if (!CONFIRM) {                 // keep what the finish needs in registers: no load when the ray ends
                             sh_L4 = r1;
                             rec = __float_as_uint(r0.w);           // float index of its light term in slot_L (shade kernel)
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
                 r = record_index(ps, chunk, i, n_rad);
                 const float4 r0 = in_q[r];
                 if (i < n_rad) { const float4 r1 = in_q[ps.qstride + r]; o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
-                else shadow_ray_of(sc, r0, o, d);
+                else shadow_ray_of(sc, ps, r0, o, d);
             }
             float t, u, v; uint32_t prim;
             octree_intersect(sc, o, d, t, u, v, prim);
@@ -494,7 +494,7 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
         primary_sample(cam, ps, film_n, sample_index, pixel, sampleno, o, d);
     } else {
         const float4 r0 = ld4<3>(&in_q[r]);
-        if (shadow) shadow_ray_of(sc, r0, o, d);
+        if (shadow) shadow_ray_of(sc, ps, r0, o, d);
         else { const float4 r1 = ld4<3>(&in_q[ps.qstride + r]); o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
     }
     const float4 h = ld4<3>(&hits[r]);
@@ -628,15 +628,14 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
         if (PRIMARY) {
             // zero the slots this chunk uses: a node whose shadow ray is blocked, or that is never
             // reached, must read back as black (mod.rs:99-100, 170)
-            const uint32_t per = ps.nodes_per_sample * sc.nlights * 3u;
-            float* z = slot_L + (size_t)chunk * ps.chunk * per;
-            const uint32_t total = cnt * per;
-            if ((((size_t)chunk * ps.chunk * per) & 3u) == 0u) {               // 16-byte aligned chunk base: wide stores
+            // (slot_L is node-major: plane q = node * nlights + light holds the term of every slot, 12 B each, so that the
+            // stores of a round — one node level — fill whole cache lines instead of 12 B of every 60)
+            const uint32_t planes = ps.nodes_per_sample * sc.nlights, total = cnt * 3u;
+            for (uint32_t q = 0; q < planes; ++q) {
+                float* z = slot_L + 3ull * ((size_t)q * ps.nslots + (size_t)chunk * ps.chunk);     // 16-byte aligned: nslots and ps.chunk are multiples of 4
                 float4* z4 = (float4*)z;
                 for (uint32_t k = (uint32_t)lane; k < total / 4u; k += 64u) st4<2>(&z4[k], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 for (uint32_t k = (total & ~3u) + (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
-            } else {
-                for (uint32_t k = (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -689,7 +688,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                 const uint32_t oi = wave_append(want, out_back, n_new);
                 if (want && out_front + oi < ps.region) {
                     const size_t r = base + (ps.region - 1u - oi);
-                    const uint32_t term = 3u * ((slot * ps.nodes_per_sample + node) * sc.nlights + li);    // float index in slot_L (< 2^32: renderer.cpp)
+                    const uint32_t term = 3u * ((node * sc.nlights + li) * ps.nslots + slot);             // float index in slot_L (< 2^32: renderer.cpp)
                     st4<2>(&out_q[r], make_float4(hp.x, hp.y, hp.z, __uint_as_float(term)));
                     st4<2>(&out_q[ps.qstride + r], make_float4(c.x, c.y, c.z, 0.0f));
                 }
@@ -786,7 +785,7 @@ __device__ f3 node_radiance(const float* __restrict__ L, const DPass& ps, uint32
     const uint32_t node = ps.level_first[level] + index;
     f3 rad = mk3(0.0f, 0.0f, 0.0f);                                    // accum_color, mod.rs:211
     for (uint32_t li = 0; li < nlights; ++li) {
-        const float* p = L + 3ull * ((size_t)node * nlights + li);
+        const float* p = L + 3ull * ((size_t)node * nlights + li) * ps.nslots;
         rad = add3(rad, mk3(p[0], p[1], p[2]));                         // mod.rs:254
     }
     if constexpr (REC == 0) {
@@ -826,7 +825,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
     const int group_lane0 = lane_id() & ~(int)(kResolveLanes - 1u);
     for (uint32_t s0 = 0; s0 < spp; s0 += kResolveLanes) {
         const uint32_t sl = s0 + j < spp ? sample_slot[(s0 + j) * ps.npix + p] : 0xFFFFFFFFu;
-        const float* L = slot_L + 3ull * ((size_t)sl * ps.nodes_per_sample * nlights);
+        const float* L = slot_L + 3ull * (size_t)sl;       // the slot's entry of plane 0; plane q is 3 * q * nslots floats further
         f3 c = mk3(0.0f, 0.0f, 0.0f);                                   // primary miss: RGB::black(), mod.rs:100
         if (sl != 0xFFFFFFFFu) switch (ps.recursions) {
             case 0: c = node_radiance<0>(L, ps, nlights, 0, 0); break;
@@ -880,7 +879,7 @@ __device__ __forceinline__ void resolve_chunk_1spp(const DPass& ps, uint32_t wid
         const uint32_t p = chunk * ps.chunk + i;                         // 1 sample per pixel: sample index == pixel index of the pass
         const uint32_t pixel = pass_pixel(ps, width, p);
         const uint32_t sl = sample_slot[p];
-        const float* L = slot_L + 3ull * ((size_t)sl * ps.nodes_per_sample * nlights);
+        const float* L = slot_L + 3ull * (size_t)sl;       // the slot's entry of plane 0; plane q is 3 * q * nslots floats further
         f3 c = mk3(0.0f, 0.0f, 0.0f);                                    // primary miss: RGB::black(), mod.rs:100
         if (sl != 0xFFFFFFFFu) switch (ps.recursions) {
             case 0: c = node_radiance<0>(L, ps, nlights, 0, 0); break;

@@ -470,6 +470,7 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     ps.rows = d_rows; ps.row0 = row0; ps.row_wrap = row_wrap; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
     ps.seed = (uint32_t)cfg.seed; ps.flags = cfg.flags; ps.recursions = cfg.recursions; ps.spread = cfg.spread;
     ps.nodes_per_sample = nodes_per_sample;
+    ps.nslots = (uint32_t)((nsamples + chunk - 1) / chunk) * chunk;
     std::memcpy(ps.level_first, level_first, sizeof ps.level_first);
     ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
     ps.chunk = chunk; ps.nchunks = (uint32_t)((nsamples + chunk - 1) / chunk); ps.region = chunk * records_per_sample_;
@@ -995,8 +996,10 @@ bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, fl
     std::vector<float> raw((size_t)nodes_per_sample * nl * 3);
     uint32_t sl = 0xFFFFFFFFu;
     HIP_TRY(hipMemcpy(&sl, slices_[0].d_sample_slot, 4, hipMemcpyDeviceToHost));
-    if (sl != 0xFFFFFFFFu) HIP_TRY(hipMemcpy(raw.data(), slices_[0].d_slot_L + (size_t)sl * raw.size(), raw.size() * 4, hipMemcpyDeviceToHost));
-    else std::fill(raw.begin(), raw.end(), 0.0f);
+    std::fill(raw.begin(), raw.end(), 0.0f);
+    if (sl != 0xFFFFFFFFu)         // slot_L is node-major: plane q = node * nlights + light, chunk_ slots in this one-sample pass
+        for (size_t q = 0; q < (size_t)nodes_per_sample * nl; ++q)
+            HIP_TRY(hipMemcpy(raw.data() + 3 * q, slices_[0].d_slot_L + 3 * (q * chunk_ + sl), 12, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(color3, d_debug_color_, 12, hipMemcpyDeviceToHost));
     for (uint32_t nd = 0; nd < nodes_per_sample; ++nd) {
         float acc[3] = { 0.0f, 0.0f, 0.0f };
