@@ -306,8 +306,34 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         // A refill makes the wave wait for ray records that come from HBM, so it is done only when
         // at least ps.refill_threshold lanes are idle (or nothing is left to do): the other waves of
         // the SIMD then have enough work to cover the wait.
-        unsigned long long idle = __ballot(rs.node == kNodeIdle);
+        unsigned long long idle = __ballot(rs.node <= kNodeFin);        // no ray, or a finished one (the two most negative codes)
         if ((uint32_t)__popcll(idle) < ps.refill_threshold && idle != ~0ull) idle = 0ull;
+        if (idle != 0ull) {
+            if (rs.node == kNodeFin) {     // ---- results of the rays that ended since the last refill (they waited in their lanes: one store section per refill, well filled)
+                rs.node = kNodeIdle;
+                if (CONFIRM && sc.oct_single_leaf) {
+                    // The reference's octree is ONE leaf (at most triangles_per_leaf triangles in the scene, e.g. 4boxes): the leaf
+                    // lists every triangle, so its closest hit IS the true closest hit and the octree's whole answer is the
+                    // contains test of OCT:160-169 on the root cube.  Settled right here: no confirm launch for such scenes.
+                    bool hit = rs.prim != kMiss;
+                    if (hit) hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]),
+                                                 add3(rs.o, vscale(rs.d, rs.t)));
+                    if (rs.occ < 0) {                                           // radiance ray
+                        st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), hit ? rs.prim : kMiss);
+                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
+                    } else if (!(hit && rs.t > 0.01f && rs.t < 1.0f)) {          // shadow ray, not blocked (mod.rs:226-232)
+                        store_unblocked(ps, rec, in_q, slot_L);
+                    }
+                } else
+                if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
+                    st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), rs.prim);     // 4 B for every ray, the 16 B record only for hits
+                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
+                } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
+                    float* dst = slot_L + rec;
+                    dst[0] = rs.t; dst[1] = rs.u; dst[2] = rs.v;
+                }
+            }
+        }
         while (idle != 0ull && !exhausted) {
             if (w_next >= w_ntot) {
                 uint32_t c = 0u;
@@ -381,33 +407,6 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
             { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, acc_tris); if (COUNT) ++acc_le; }
-        const bool fin = rs.node == kNodeFin;
-        if (__ballot(fin) != 0ull) {
-            if (fin) {
-                rs.node = kNodeIdle;
-                if (CONFIRM && sc.oct_single_leaf) {
-                    // The reference's octree is ONE leaf (at most triangles_per_leaf triangles in the scene, e.g. 4boxes): the leaf
-                    // lists every triangle, so its closest hit IS the true closest hit and the octree's whole answer is the
-                    // contains test of OCT:160-169 on the root cube.  Settled right here: no confirm launch for such scenes.
-                    bool hit = rs.prim != kMiss;
-                    if (hit) hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]),
-                                                 add3(rs.o, vscale(rs.d, rs.t)));
-                    if (rs.occ < 0) {                                           // radiance ray
-                        st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), hit ? rs.prim : kMiss);
-                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
-                    } else if (!(hit && rs.t > 0.01f && rs.t < 1.0f)) {          // shadow ray, not blocked (mod.rs:226-232)
-                        store_unblocked(ps, rec, in_q, slot_L);
-                    }
-                } else
-                if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
-                    st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), rs.prim);     // 4 B for every ray, the 16 B record only for hits
-                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
-                } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
-                    float* dst = slot_L + rec;
-                    dst[0] = rs.t; dst[1] = rs.u; dst[2] = rs.v;
-                }
-            }
-        }
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { acc_nodes += __shfl_down((int)acc_nodes, off, 64); acc_tris += __shfl_down((int)acc_tris, off, 64); }
