@@ -126,10 +126,23 @@ uint32_t half_bits_directed(float x, bool up)
     }
     return b;
 }
+// experiment knob (profiles/r02_notes.md): MI355RT_BOX_EXTRA_ULPS=n moves every bound n more half-precision steps outward —
+// how much do the node visits per ray depend on the quantisation of the boxes?
+uint32_t step_outward(uint32_t b, bool up, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        if ((b & 0x7FFFu) >= 0x7BFFu) break;
+        if ((b & 0x7FFFu) == 0) b = up ? 0x0001u : 0x8001u;
+        else if (((b & 0x8000u) == 0) == up) b += 1;
+        else b -= 1;
+    }
+    return b;
+}
 void pack_box(const Box& box, float pad, uint32_t out[3])
 {
+    static const int extra = [] { const char* e = getenv("MI355RT_BOX_EXTRA_ULPS"); return e ? atoi(e) : 0; }();
     for (int a = 0; a < 3; ++a)
-        out[a] = half_bits_directed(box.mn[a] - pad, false) | (half_bits_directed(box.mx[a] + pad, true) << 16);
+        out[a] = step_outward(half_bits_directed(box.mn[a] - pad, false), false, extra) | (step_outward(half_bits_directed(box.mx[a] + pad, true), true, extra) << 16);
 }
 
 }  // namespace

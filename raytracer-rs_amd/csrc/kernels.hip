@@ -286,6 +286,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                                            DCounters* counters, int* stack, uint32_t single_chunk, uint32_t single_nrad, uint32_t single_nshadow)
 {
     uint32_t acc_nodes = 0, acc_tris = 0, acc_ie = 0, acc_le = 0;
+    uint32_t acc_li = 0, acc_ll = 0, acc_ld = 0, acc_it = 0, acc_rf = 0, acc_rp = 0, acc_rr = 0;       // COUNT only: lane census per iteration, refill statistics
     unsigned long long t_begin = 0;
     if (COUNT) t_begin = __builtin_amdgcn_s_memrealtime();
 
@@ -308,6 +309,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         // the SIMD then have enough work to cover the wait.
         unsigned long long idle = __ballot(rs.node <= kNodeFin);        // no ray, or a finished one (the two most negative codes)
         if ((uint32_t)__popcll(idle) < ps.refill_threshold && idle != ~0ull) idle = 0ull;
+        if (COUNT && idle != 0ull) ++acc_rf;
         if (idle != 0ull) {
             if (rs.node == kNodeFin) {     // ---- results of the rays that ended since the last refill (they waited in their lanes: one store section per refill, well filled)
                 rs.node = kNodeIdle;
@@ -356,6 +358,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                 continue;
             }
             const uint32_t avail = w_ntot - w_next;
+            if (COUNT) { ++acc_rp; acc_rr += min((uint32_t)__popcll(idle), avail); }
             const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
             if (rs.node == kNodeIdle && rank < avail) {
                 const uint32_t i = w_next + rank;
@@ -392,6 +395,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
             idle = __ballot(rs.node == kNodeIdle);
         }
         if (__ballot(rs.node != kNodeIdle) == 0ull) break;
+        if (COUNT) { acc_li += (uint32_t)__popcll(__ballot(lane_at_inner(rs))); acc_ll += (uint32_t)__popcll(__ballot(lane_at_leaf(rs))); acc_ld += (uint32_t)__popcll(__ballot(rs.node <= kNodeFin)); ++acc_it; }
 
         // ---- while-while scheduling: inner-node steps run for the lanes at inner nodes; lanes that
         // reached a leaf wait until enough of them are there (or nobody is left at an inner node),
@@ -414,6 +418,9 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         if (lane_id() == 0) {
             atomicAdd(&cs->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&cs->tris_tested, (unsigned long long)acc_tris);
             atomicAdd(&cs->inner_execs, (unsigned long long)acc_ie); atomicAdd(&cs->leaf_execs, (unsigned long long)acc_le);
+            atomicAdd(&cs->lanes_inner, (unsigned long long)acc_li); atomicAdd(&cs->lanes_leaf, (unsigned long long)acc_ll); atomicAdd(&cs->lanes_done, (unsigned long long)acc_ld);
+            atomicAdd(&cs->lane_samples, (unsigned long long)acc_it); atomicAdd(&cs->refills, (unsigned long long)acc_rf); atomicAdd(&cs->refill_passes, (unsigned long long)acc_rp);
+            atomicAdd(&cs->refill_rays, (unsigned long long)acc_rr);
             // load-balance diagnostics: when did this wave run out of work, relative to the first wave's start
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
             DCounters* c0 = &counters[0];

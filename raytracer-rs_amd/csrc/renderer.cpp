@@ -543,6 +543,21 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
         DCounters c0{};
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(&c0, d_counters_, sizeof c0, hipMemcpyDeviceToHost));
+        {   // lane census of the launch (summed over the counter shards; cumulative over the call's launches: print differences)
+            DCounters sh[kShards], t{};
+            HIP_TRY(hipMemcpy(sh, d_counters_, sizeof sh, hipMemcpyDeviceToHost));
+            for (const DCounters& x : sh) { t.lanes_inner += x.lanes_inner; t.lanes_leaf += x.lanes_leaf; t.lanes_done += x.lanes_done; t.lane_samples += x.lane_samples;
+                                            t.refills += x.refills; t.refill_passes += x.refill_passes; t.refill_rays += x.refill_rays; t.inner_execs += x.inner_execs; t.leaf_execs += x.leaf_execs; }
+            static DCounters prev{};
+            if (t.lane_samples < prev.lane_samples) prev = DCounters{};
+            const double it = (double)(t.lane_samples - prev.lane_samples);
+            if (it > 0)
+                fprintf(stderr, "[mi355rt] trace round %u census: iterations %.0f, lanes at inner %.1f / at leaf %.1f / idle-or-finished %.1f per iteration; inner execs %.2f, leaf execs %.2f per iteration; refills %llu, passes %llu, rays per refill %.1f\n",
+                        r, it, (t.lanes_inner - prev.lanes_inner) / it, (t.lanes_leaf - prev.lanes_leaf) / it, (t.lanes_done - prev.lanes_done) / it,
+                        (t.inner_execs - prev.inner_execs) / it, (t.leaf_execs - prev.leaf_execs) / it,
+                        t.refills - prev.refills, t.refill_passes - prev.refill_passes, (double)(t.refill_rays - prev.refill_rays) / std::max<double>(1.0, (double)(t.refills - prev.refills)));
+            prev = t;
+        }
         if (c0.n_waves)
             fprintf(stderr, "[mi355rt] trace round %u: %llu waves, mean wave busy %.1f us, first wave out of work at %.1f us, last at %.1f us\n", r, c0.n_waves,
                     (double)c0.t_sum_end / c0.n_waves / 100.0, (double)(c0.t_first_end - c0.t_start) / 100.0, (double)(c0.t_last_end - c0.t_start) / 100.0);
