@@ -732,9 +732,10 @@ bool Renderer::render(uint32_t spp)
     if (!begin_call()) return false;
     const uint32_t nrows = (uint32_t)owned_rows.size();
     if (nrows && spp) {
-        // concurrent frame slices: not worth their extra launches below ~1 Mi samples per slice
+        // concurrent frame slices: worth their extra launches from ~32 Mi samples per slice on (measured on one rank's share of a
+        // strong-scaled 1080p x 64 frame, tools/strong_slices_probe.py: 17 / 35 / 71 / 133 M samples are fastest with 1 / 1-2 / 2 / 2-3 slices)
         uint32_t nsl = std::max(1u, std::min(slices, kMaxSlices));
-        if (!slices_explicit) nsl = (uint32_t)std::min<uint64_t>(nsl, std::max<uint64_t>(1, (uint64_t)nrows * cfg.width * spp >> 20));
+        if (!slices_explicit) nsl = (uint32_t)std::min<uint64_t>(nsl, std::max<uint64_t>(1, (uint64_t)nrows * cfg.width * spp >> 25));
         nsl = std::min(nsl, (nrows + cfg.stripe_rows - 1) / cfg.stripe_rows);
         if (!assign_slice_rows(nsl)) return false;
         size_t target = (size_t)48 << 20;                               // samples per pass of one slice
