@@ -48,7 +48,7 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 #define MI355RT_SHADE_P_BLOCKS 5               // blocks per CU the shade kernels are compiled for and launched with (A/B knobs)
 #endif
 #ifndef MI355RT_SHADE_S_BLOCKS
-#define MI355RT_SHADE_S_BLOCKS 8
+#define MI355RT_SHADE_S_BLOCKS 7
 #endif
 #ifndef MI355RT_SHADE_PULL
 #define MI355RT_SHADE_PULL 0                   // 0: like the trace kernel (ps.pull_mode); 2: static striding
@@ -597,6 +597,28 @@ __global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel
     }
 }
 
+// The walk of mod.rs:187-189 / sample_generator.rs:27 — take the first entry from jx on (wrapping at 65535) that lies in the
+// hemisphere of n.  tv = table[jx] is already loaded; the rest is fetched FOUR entries at a time: as a loop of single dependent
+// loads it runs as long as the unluckiest lane of the wave (~7 cache latencies); four consecutive entries are one or two lines.
+__device__ __forceinline__ void hemisphere_walk(const float4* __restrict__ table, const f3 n, uint32_t& jx, float4& tv)
+{
+    for (uint32_t guard = 0u; tv.x * n.x + tv.y * n.y + tv.z * n.z <= 0.0f && guard < kNumSamples; guard += 4u) {
+        const uint32_t j1 = jx + 1u == kSampleMax ? 0u : jx + 1u;
+        const uint32_t j2 = j1 + 1u == kSampleMax ? 0u : j1 + 1u;
+        const uint32_t j3 = j2 + 1u == kSampleMax ? 0u : j2 + 1u;
+        const uint32_t j4 = j3 + 1u == kSampleMax ? 0u : j3 + 1u;
+        const float4 t1 = table[j1], t2 = table[j2], t3 = table[j3], t4 = table[j4];
+        const bool r1 = t1.x * n.x + t1.y * n.y + t1.z * n.z <= 0.0f, r2 = t2.x * n.x + t2.y * n.y + t2.z * n.z <= 0.0f;
+        const bool r3 = t3.x * n.x + t3.y * n.y + t3.z * n.z <= 0.0f;
+        // the reference stops at the first accepted entry, or after kNumSamples steps with whatever it holds
+        const uint32_t left = kNumSamples - guard;           // steps still allowed (>= 1)
+        if (!r1 || left == 1u) { tv = t1; jx = j1; break; }
+        if (!r2 || left == 2u) { tv = t2; jx = j2; break; }
+        if (!r3 || left == 3u) { tv = t3; jx = j3; break; }
+        tv = t4; jx = j4;
+    }
+}
+
 // ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
 // Shade the hits of one chunk (one wave): see the header of this file.
 // in_nrad: radiance rays of the chunk in in_q (ignored for PRIMARY); out_nrad / out_nshadow: what was appended to out_q.
@@ -703,43 +725,38 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             if (level < ps.recursions) {
                 const uint32_t k = ps.spread * (ps.recursions - level);                // num_sub_rays, mod.rs:150
                 const uint32_t index_in_level = node - ps.level_first[level];
-                for (uint32_t ci = 0; ci < k; ++ci) {
-                    const uint32_t child_node = ps.level_first[level + 1] + index_in_level * k + ci;
-                    f3 bo = mk3(0, 0, 0), bd = mk3(0, 0, 1);
+                // children in pairs: both first table entries are in flight before either walk starts (the walks are chains of
+                // dependent cache accesses; one after the other they were most of this kernel's latency)
+                for (uint32_t ci = 0; ci < k; ci += 2u) {
+                    const bool two = ci + 1u < k;
+                    const uint32_t child0 = ps.level_first[level + 1] + index_in_level * k + ci, child1 = child0 + 1u;
+                    f3 bo0 = mk3(0, 0, 0), bd0 = mk3(0, 0, 1), bo1 = bo0, bd1 = bd0;
                     if (active) {
-                        uint32_t h0 = pixel, h1 = sampleno, h2 = 1u + child_node, h3 = ps.seed;
-                        pcg4d(h0, h1, h2, h3);
-                        uint32_t jx = __umulhi(h0, 65535u);                            // uniform in [0, 65534], sample_generator.rs:32
                         const float4* __restrict__ table = (const float4*)sc.table;
-                        // The walk of mod.rs:187-189 / sample_generator.rs:27 — take the first entry from jx on
-                        // (wrapping at 65535) that lies in the hemisphere of n — fetched FOUR entries at a time:
-                        // as a loop of single dependent loads it runs as long as the unluckiest lane of the wave
-                        // (~7 cache latencies per child); four consecutive entries are one or two cache lines.
-                        float4 tv = table[jx];
-                        for (uint32_t guard = 0u; tv.x * n.x + tv.y * n.y + tv.z * n.z <= 0.0f && guard < kNumSamples; guard += 4u) {
-                            const uint32_t j1 = jx + 1u == kSampleMax ? 0u : jx + 1u;
-                            const uint32_t j2 = j1 + 1u == kSampleMax ? 0u : j1 + 1u;
-                            const uint32_t j3 = j2 + 1u == kSampleMax ? 0u : j2 + 1u;
-                            const uint32_t j4 = j3 + 1u == kSampleMax ? 0u : j3 + 1u;
-                            const float4 t1 = table[j1], t2 = table[j2], t3 = table[j3], t4 = table[j4];
-                            const bool r1 = t1.x * n.x + t1.y * n.y + t1.z * n.z <= 0.0f, r2 = t2.x * n.x + t2.y * n.y + t2.z * n.z <= 0.0f;
-                            const bool r3 = t3.x * n.x + t3.y * n.y + t3.z * n.z <= 0.0f;
-                            // the reference stops at the first accepted entry, or after kNumSamples steps with whatever it holds
-                            const uint32_t left = kNumSamples - guard;           // steps still allowed (>= 1)
-                            if (!r1 || left == 1u) { tv = t1; jx = j1; break; }
-                            if (!r2 || left == 2u) { tv = t2; jx = j2; break; }
-                            if (!r3 || left == 3u) { tv = t3; jx = j3; break; }
-                            tv = t4; jx = j4;
+                        uint32_t a0 = pixel, a1 = sampleno, a2 = 1u + child0, a3 = ps.seed;
+                        pcg4d(a0, a1, a2, a3);
+                        uint32_t jx0 = __umulhi(a0, 65535u), jx1 = jx0;                  // uniform in [0, 65534], sample_generator.rs:32
+                        if (two) {
+                            uint32_t b0 = pixel, b1 = sampleno, b2 = 1u + child1, b3 = ps.seed;
+                            pcg4d(b0, b1, b2, b3);
+                            jx1 = __umulhi(b0, 65535u);
                         }
-                        bd = mk3(tv.x, tv.y, tv.z);
-                        bo = add3(hp, sscale(0.00001f, bd));                           // mod.rs:192-193
+                        float4 tv0 = table[jx0], tv1 = table[jx1];
+                        hemisphere_walk(table, n, jx0, tv0);
+                        if (two) hemisphere_walk(table, n, jx1, tv1);
+                        bd0 = mk3(tv0.x, tv0.y, tv0.z); bo0 = add3(hp, sscale(0.00001f, bd0));   // mod.rs:192-193
+                        bd1 = mk3(tv1.x, tv1.y, tv1.z); bo1 = add3(hp, sscale(0.00001f, bd1));
                     }
-                    uint32_t n_new;
-                    const uint32_t oi = wave_append(active, out_front, n_new);
-                    if (active && oi + out_back < ps.region + 0u) {
-                        const size_t r = base + oi;
-                        st4<2>(&out_q[r], make_float4(bo.x, bo.y, bo.z, bd.x));
-                        st4<2>(&out_q[ps.qstride + r], make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8))));
+                    for (uint32_t w = 0; w < (two ? 2u : 1u); ++w) {
+                        const f3 bo = w ? bo1 : bo0, bd = w ? bd1 : bd0;
+                        const uint32_t child_node = w ? child1 : child0;
+                        uint32_t n_new;
+                        const uint32_t oi = wave_append(active, out_front, n_new);
+                        if (active && oi + out_back < ps.region + 0u) {
+                            const size_t r = base + oi;
+                            st4<2>(&out_q[r], make_float4(bo.x, bo.y, bo.z, bd.x));
+                            st4<2>(&out_q[ps.qstride + r], make_float4(bd.y, bd.z, __uint_as_float(slot), __uint_as_float(((level + 1u) << 4) | (child_node << 8))));
+                        }
                     }
                 }
             }
