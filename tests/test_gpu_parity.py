@@ -459,6 +459,35 @@ def test_empty_single_triangle_and_multi_light_scenes(pkg, oracle, scenes, sem, 
     assert np.array_equal(bits(rto.film.pixel_datas()[0]), bits(orco.film()[0]))
 
 
+@pytest.mark.parametrize("name,nlights,rec", [("ico2", 2, 2), ("ico3_tex", 3, 1), ("thai2", 2, 2)])
+def test_several_lights_on_multi_leaf_octrees(pkg, oracle, scenes, sem3, name, nlights, rec):
+    """Several lights where the octree has many leaves, i.e. through the confirm kernel (the 48-triangle scenes above settle
+    the octree inside the trace kernel): a shadow record holds only the hit point and the index of its light term, its ray is
+    rebuilt from the light that index belongs to (term = 3 * ((node * nlights + light) * slots + slot)), and slot_L has one plane
+    per (node, light).  Whole frames, 50-row frames (the fused kernel) and per-node terms against the oracle, bit for bit."""
+    sc = dict(scenes(name))
+    base = sc["lights"][0].copy()
+    extra = np.array([[-3.0, 4.0, -2.0, 2.0, 5.0, 8.0], [6.0, -2.5, 3.0, 4.0, 1.0, 0.5]], np.float32)
+    sc["lights"] = np.concatenate([base[None, :], extra[: nlights - 1]]).astype(np.float32)
+    w, h = 96, 70
+    rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=11, recursions=rec, flags=sem3.gpu)
+    orc = oracle.Oracle(sc, w, h, seed=11, recursions=rec, flags=sem3.orc)
+    c = rt.render(3); oc = orc.render(3, nthreads=4)
+    assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+    assert c.shadow > c.primary_hits                       # more than one shadow ray per shading point somewhere
+    for _ in range(3):
+        assert rt.trace_frame_additive() == orc.trace_frame_additive()
+    gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+    assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+    assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
+    hit = 0
+    for pixel in range(w * 10 + 5, w * h, 397):
+        gc, gl = rt.debug_sample(pixel, 7); ocol, ol, ohit = orc.sample_debug(pixel, 7)
+        assert np.array_equal(bits(gc), bits(ocol)) and np.array_equal(bits(gl), bits(ol)), pixel
+        hit += int(ohit[0])
+    assert hit > 0
+
+
 def test_tiny_and_odd_image_sizes(pkg, oracle, scenes, sem):
     """1x1, 1xN, Nx1 and sizes that are not multiples of the chunk / stripe / wave sizes."""
     for w, h in ((1, 1), (1, 37), (37, 1), (257, 3), (33, 65)):
