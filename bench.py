@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline PMC fields become null)")
     ap.add_argument("--native-gather", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: gather the stripes with the library's own RCCL path (on), torch.distributed (off), or try native first")
+    ap.add_argument("--device-lbvh", action="store_true", help="MI355RT_FLAG_DEVICE_LBVH: BVH built on the device (Morton order) instead of the host's SAH build")
     ap.add_argument("--true-closest-hit", action="store_true",
                     help="MI355RT_FLAG_TRUE_CLOSEST_HIT: NoAccelerationIntersector semantics (no octree confirm step) instead of the reference's default intersector")
     ap.add_argument("--fix-row-index", action="store_true",
@@ -231,7 +232,7 @@ def main():
     width, height = (3840, 2160) if args.config == "c5" else (WIDTH, HEIGHT)
     base_spp = args.spp or (256 if args.config == "c5" else SPP)
     spp = base_spp * world if args.scaling == "weak" else base_spp
-    sem_flag = pkg.FLAG_TRUE_CLOSEST_HIT if args.true_closest_hit else 0
+    sem_flag = (pkg.FLAG_TRUE_CLOSEST_HIT if args.true_closest_hit else 0) | (pkg.FLAG_DEVICE_LBVH if args.device_lbvh else 0)
     rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, width, height, seed=1, device=local_rank,
                                           stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_world=world, flags=sem_flag)
     base_flags = (pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0) | sem_flag
@@ -332,7 +333,7 @@ def main():
     other = None
     if world == 1:
         del rt
-        oflag = 0 if args.true_closest_hit else pkg.FLAG_TRUE_CLOSEST_HIT
+        oflag = (0 if args.true_closest_hit else pkg.FLAG_TRUE_CLOSEST_HIT) | (pkg.FLAG_DEVICE_LBVH if args.device_lbvh else 0)
         rt2 = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, width, height, seed=1, device=local_rank, flags=oflag)
         rt2.set_flags(oflag | (pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0))
         if args.slices:
@@ -441,6 +442,8 @@ def main():
             "gather_ms_rank0": round(sorted(gather_ms)[len(gather_ms) // 2], 3) if gather_ms else None,
             "other_semantics": other,
             "roofline": roof,
+            "accel": dict(acc, builder=("device LBVH (MI355RT_FLAG_DEVICE_LBVH)" if rt.bvh_build_info()["on_device"] else "host binned SAH"),
+                          device_build_ms=rt.bvh_build_info()["device_ms"]),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ge, scene, width, height, args.fix_row_index)

@@ -52,6 +52,12 @@ extern "C" {
 /* CREATE-time flag, testing only: the members of a device group (config.device_count > 1) all use config.device
  * instead of consecutive devices, so that the group's decomposition and gather run on a single-GPU machine. */
 #define MI355RT_FLAG_GROUP_SHARES_DEVICE 16u
+/* Create-time: build the BVH on the device (Morton order, Karras' parallel hierarchy, bottom-up refit: csrc/lbvh.hip) instead
+ * of the host's binned-SAH build — the replacement north_star names for oct_tree_intersector.rs:66-146.  Results are identical
+ * (any conservative tree gives the same hits); a frame is slower (Morton-order trees cost more node visits per ray) and create
+ * is faster on large scenes.  Falls back to the host build when the device tree would be deeper than the traversal stack or the
+ * scene fits one leaf; mi355rt_accel_stats out[6] then reports the host build's time and mi355rt_last_error says why. */
+#define MI355RT_FLAG_DEVICE_LBVH 64u
 
 typedef struct mi355rt_handle mi355rt_handle;
 
@@ -229,9 +235,13 @@ int mi355rt_debug_slab(mi355rt_handle* h, const float* inv_rays6, const float* c
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
 
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,
- * [4] node bytes, [5] triangle bytes, [6] host BVH build time inside create (microseconds), [7] host octree build
- * time inside create (microseconds; 0 with MI355RT_FLAG_TRUE_CLOSEST_HIT) */
+ * [4] node bytes, [5] triangle bytes, [6] BVH build time inside create (wall, microseconds; host SAH build, or the device
+ * build with its uploads and read-back), [7] host octree build time inside create (microseconds; 0 with
+ * MI355RT_FLAG_TRUE_CLOSEST_HIT) */
 int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8]);
+/* which builder made the BVH: out[0] 1 = the device (MI355RT_FLAG_DEVICE_LBVH served the scene), 0 = the host;
+ * out[1] device time of the build kernels + sort (HIP events, microseconds; 0 for a host build) */
+int mi355rt_bvh_build_info(const mi355rt_handle* h, uint32_t out[2]);
 /* the reference's octree (absent with MI355RT_FLAG_TRUE_CLOSEST_HIT): out[0] octree nodes, [1] inner, [2] leaves, [3] empty leaves, [4] depth,
  * [5] triangle references (the quantities of SURVEY.md 6.2) */
 int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8]);

@@ -32,6 +32,7 @@ FLAG_TIME_KERNELS = 4
 FLAG_OCTREE_SEMANTICS = 8
 FLAG_GROUP_SHARES_DEVICE = 16
 FLAG_TRUE_CLOSEST_HIT = 32
+FLAG_DEVICE_LBVH = 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(_HERE, "libmi355rt.so")     # MI355RT_LIB: an A/B build of the library
@@ -128,6 +129,7 @@ ABI = [
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
     ("mi355rt_octree_stats", C.c_int, [_H, _U]),
+    ("mi355rt_bvh_build_info", C.c_int, [_H, _U]),
     ("mi355rt_device_count", C.c_uint32, [_H]),
     ("mi355rt_synchronize", C.c_int, [_H]),
     ("mi355rt_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
@@ -378,6 +380,11 @@ class RayTracer:
         self._check(lib().mi355rt_accel_stats(self._h, _up(out)))
         return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), max_leaf=int(out[3]),
                     node_bytes=int(out[4]), tri_bytes=int(out[5]), bvh_build_ms=int(out[6]) / 1000.0, octree_build_ms=int(out[7]) / 1000.0)
+
+    def bvh_build_info(self):
+        out = np.zeros(2, np.uint32)
+        self._check(lib().mi355rt_bvh_build_info(self._h, _up(out)))
+        return dict(on_device=bool(out[0]), device_ms=int(out[1]) / 1000.0)
 
     def octree_stats(self):
         out = np.zeros(8, np.uint32)

@@ -6,6 +6,7 @@
 // not of the scene, and is not reproduced here ("Octree vs BVH").
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace mi355rt {
@@ -38,5 +39,9 @@ constexpr uint32_t kBvhMaxLeaf = 4;
 
 // tri_verts: ntri*9 world-space floats, tri_geom: ntri geometry indices.
 void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out);
+
+// The same structure built on the current HIP device (lbvh.hip: Morton order, Karras hierarchy, refit; MI355RT_FLAG_DEVICE_LBVH).
+// false + `why`: the device path does not serve this scene (the caller builds on the host).  ms[0] device time, ms[1] wall time.
+bool build_bvh_device(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out, std::string& why, double ms[2]);
 
 }  // namespace mi355rt

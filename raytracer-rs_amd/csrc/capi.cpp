@@ -281,6 +281,12 @@ int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8])
     out[6] = (uint32_t)(h->r->build_ms_[0] * 1000.0); out[7] = (uint32_t)(h->r->build_ms_[1] * 1000.0);
     return MI355RT_OK;
 }
+int mi355rt_bvh_build_info(const mi355rt_handle* h, uint32_t out[2])
+{
+    if (!h || !out) return MI355RT_E_INVALID;
+    out[0] = h->r->bvh_on_device_ ? 1u : 0u; out[1] = (uint32_t)(h->r->lbvh_device_ms_ * 1000.0);
+    return MI355RT_OK;
+}
 int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8])
 {
     if (!h || !out) return MI355RT_E_INVALID;

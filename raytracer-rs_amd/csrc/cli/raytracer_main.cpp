@@ -61,7 +61,7 @@ int main(int argc, char** argv)
     std::string file = "./data/thai2.dae";                           // main.rs:15
     size_t max_triangles = raytracer_lib::DEFAULT_TRIANGLES_PER_LEAF, width = DEFAULT_WIDTH, height = DEFAULT_HEIGHT;
     size_t frame_iterations = 0, spp = 0, seed = 1, gpus = 1;
-    bool have_iterations = false, fix_row = false, share_device = false;
+    bool have_iterations = false, fix_row = false, share_device = false, device_lbvh = false;
     std::string out;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -78,9 +78,10 @@ int main(int argc, char** argv)
         else if (a == "--share-device") share_device = true;
         else if (a == "--out") { if (v) out = take(); }
         else if (a == "--fix-row-index") fix_row = true;
+        else if (a == "--device-lbvh") device_lbvh = true;
         else if (a == "-h" || a == "--help") {
             std::printf("raytracer-rs (MI355X) 0.1.0\nusage: raytracer [-f COLLADA_FILENAME] [-m MAX_TRIS] [-i FRAME_ITERATIONS] [--width W] [--height H]\n"
-                        "                 [--spp N] [--seed S] [--gpus N] [--out image.ppm|image.png] [--fix-row-index]\n");
+                        "                 [--spp N] [--seed S] [--gpus N] [--out image.ppm|image.png] [--fix-row-index] [--device-lbvh]\n");
             return 0;
         }
     }
@@ -92,6 +93,7 @@ int main(int argc, char** argv)
         mi355rt_config cfg = raytracer_lib::make_config(max_triangles, width, height);
         cfg.seed = seed;
         if (fix_row) cfg.flags |= MI355RT_FLAG_FIX_ROW_INDEX;
+        if (device_lbvh) cfg.flags |= MI355RT_FLAG_DEVICE_LBVH;             // BVH built on the GPU (Morton order) instead of the host's SAH build
         cfg.device_count = (uint32_t)gpus;
         if (share_device) cfg.flags |= MI355RT_FLAG_GROUP_SHARES_DEVICE;      // testing: the whole group on one GPU
         if (gpus > 1) std::printf("rendering on %zu GPUs (rows dealt in stripes of %u)\n", gpus, cfg.stripe_rows);

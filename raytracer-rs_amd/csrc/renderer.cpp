@@ -91,7 +91,7 @@ bool Renderer::set_seed(uint64_t seed)
 // mi355rt_set_flags: run-time flags only; a create-time flag (the intersector) cannot be changed on a live handle
 bool Renderer::set_flags(uint32_t flags)
 {
-    constexpr uint32_t kCreateMask = MI355RT_FLAG_OCTREE_SEMANTICS | MI355RT_FLAG_TRUE_CLOSEST_HIT | MI355RT_FLAG_GROUP_SHARES_DEVICE;
+    constexpr uint32_t kCreateMask = MI355RT_FLAG_OCTREE_SEMANTICS | MI355RT_FLAG_TRUE_CLOSEST_HIT | MI355RT_FLAG_GROUP_SHARES_DEVICE | MI355RT_FLAG_DEVICE_LBVH;
     if ((flags ^ cfg.flags) & kCreateMask) { last_error = "the intersector flags (OCTREE_SEMANTICS, TRUE_CLOSEST_HIT) are create-time flags: they cannot be changed with mi355rt_set_flags"; return false; }
     cfg.flags = flags;
     return true;
@@ -143,7 +143,15 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
 
     // --- acceleration structure (host build, once) + per-triangle normals (calc_normal, mod.rs:198-205)
     const auto t_bvh = std::chrono::steady_clock::now();
-    build_bvh(scene.tri_verts.data(), scene.tri_geom.data(), ntri, bvh);
+    bool on_device = false;
+    if (cfg.flags & MI355RT_FLAG_DEVICE_LBVH) {
+        std::string why; double ms[2];
+        on_device = build_bvh_device(scene.tri_verts.data(), scene.tri_geom.data(), ntri, bvh, why, ms);
+        if (on_device) { lbvh_device_ms_ = ms[0]; }
+        else last_error = "device LBVH not used (" + why + "): host SAH build instead";      // not an error: create goes on
+    }
+    if (!on_device) build_bvh(scene.tri_verts.data(), scene.tri_geom.data(), ntri, bvh);
+    bvh_on_device_ = on_device;
     build_ms_[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bvh).count();
     collect_cull_boxes();
     if (bvh.max_depth > kBvhMaxDepth) { err = "internal: BVH deeper than the traversal stack"; code = MI355RT_E_INVALID; return false; }

@@ -63,7 +63,9 @@ public:
     uint32_t level_first[kMaxLevels + 1] = { 0 };
     std::vector<std::array<float, 6>> cull_boxes_;   // top BVH subtree boxes for primary-chunk culling
     uint32_t oct_stats_[8] = { 0 };       // the reference's octree: nodes, inner, leaves, empty, depth, triangle refs
-    double build_ms_[2] = { 0.0, 0.0 };   // host build times inside create: BVH (binned SAH), octree (SAT)
+    double build_ms_[2] = { 0.0, 0.0 };   // build times inside create (wall): BVH (host binned SAH, or the device build), octree (SAT, host)
+    bool bvh_on_device_ = false;          // MI355RT_FLAG_DEVICE_LBVH and the device build served the scene
+    double lbvh_device_ms_ = 0.0;         // its device time (kernels + sort)
     enum Mode { kModeConfirm = 0, kModeOctreeWalk = 1, kModeTrueClosest = 2 };
     Mode mode_ = kModeConfirm;            // intersector semantics, fixed at creation
 

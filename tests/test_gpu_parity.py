@@ -729,3 +729,69 @@ def test_randomised_configurations_match_oracle(pkg, scenes, oracle):
         assert np.array_equal(gn[m], on[m]), desc
         assert np.array_equal(bits(gs[m]), bits(os_[m])) and np.array_equal(bits(gq[m]), bits(oq[m])), desc
         assert np.array_equal(rt.get_tonemapped_pixels()[m], orc.get_tonemapped_pixels()[m]), desc
+
+
+# ---- device LBVH (MI355RT_FLAG_DEVICE_LBVH): a different tree, the same results ---------------------------------
+@pytest.mark.parametrize("name", ["ico2", "ico3_tex", "thai2"])
+def test_device_lbvh_gives_the_same_results(pkg, scenes, oracle, sem, name):
+    """The BVH built on the device (Morton order, Karras hierarchy, refit: csrc/lbvh.hip) instead of the host's SAH build:
+    closest hits against the brute-force oracle on 40 000 rays, whole frames + 50-row frames against the oracle bit for bit
+    in both semantics, and the builder reports that it ran on the device."""
+    sc = scenes(name)
+    w, h = 80, 64
+    rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=5, flags=sem.gpu | pkg.FLAG_DEVICE_LBVH)
+    info = rt.bvh_build_info(); st = rt.accel_stats()
+    assert info["on_device"] and info["device_ms"] > 0.0 and st["max_depth"] <= 31 and st["max_leaf"] == 1
+    print("\n[%s] device LBVH: %d nodes, %d leaves, depth %d, device %.3f ms, wall %.3f ms" % (name, st["nodes"], st["leaves"], st["max_depth"], info["device_ms"], st["bvh_build_ms"]))
+    host = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=5, flags=sem.gpu)
+    assert not host.bvh_build_info()["on_device"]
+    rng = np.random.default_rng(3)
+    v = np.asarray(sc["tri_verts"], np.float32).reshape(-1, 3); lo, hi = v.min(0), v.max(0)
+    org = rng.uniform(lo - 0.5 * (hi - lo), hi + 0.5 * (hi - lo), (40000, 3)); tgt = rng.uniform(lo, hi, (40000, 3))
+    rays = np.concatenate([org, tgt - org], axis=1).astype(np.float32)
+    g_tuv, g_prim = rt.intersect_rays(rays); h_tuv, h_prim = host.intersect_rays(rays)
+    assert np.array_equal(g_prim, h_prim) and np.array_equal(bits(g_tuv[g_prim != 0xFFFFFFFF]), bits(h_tuv[h_prim != 0xFFFFFFFF]))
+    orc = oracle.Oracle(sc, w, h, seed=5, flags=sem.orc)
+    c = rt.render(3); oc = orc.render(3, nthreads=4)
+    assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+    for _ in range(2):
+        assert rt.trace_frame_additive() == orc.trace_frame_additive()
+    gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+    assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+    assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels())
+
+
+def test_device_lbvh_falls_back_on_one_leaf_scenes_and_builds_large_ones(pkg, scenes, oracle):
+    """A 3-triangle scene fits one leaf: the host build serves it (create succeeds, the flag is a request).  4boxes (48 triangles)
+    and the 120 000-triangle random scene are built on the device; closest hits and a frame equal the host tree's."""
+    sc = dict(scenes("4boxes")); sc["tri_verts"] = sc["tri_verts"][:3].copy(); sc["tri_geom"] = sc["tri_geom"][:3].copy()
+    rt = pkg.create_raytracer_from_arrays(sc, 70, 32, 32, seed=1, flags=pkg.FLAG_DEVICE_LBVH)
+    assert not rt.bvh_build_info()["on_device"]
+    orc = oracle.Oracle(sc, 32, 32, seed=1)
+    rt.render(2); orc.render(2, nthreads=2)
+    assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0]))
+    rt4 = pkg.create_raytracer_from_arrays(scenes("4boxes"), 70, 32, 32, seed=1, flags=pkg.FLAG_DEVICE_LBVH)
+    assert rt4.bvh_build_info()["on_device"]
+    # 120 000 small triangles spread evenly: built on the device.  The crowded scene of test_large_random_scene_deep_tree gives a
+    # Morton-order tree deeper than the traversal stack (31 levels): the host build serves it, results as ever.
+    rng = np.random.default_rng(7)
+    big = dict(scenes("4boxes"))
+    lo, hi = big["tri_verts"].reshape(-1, 3).min(0), big["tri_verts"].reshape(-1, 3).max(0)
+    centre = rng.uniform(lo, hi, size=(120000, 1, 3))
+    big["tri_verts"] = (centre + rng.uniform(-1.0, 1.0, size=(120000, 3, 3)) * 0.01 * (hi - lo).max()).astype(np.float32).reshape(120000, 9)
+    big["tri_geom"] = rng.integers(0, len(big["mat_kind"]), size=120000).astype(np.uint32)
+    for label, sc_big, expect_device in (("even", big, True), ("crowded", _random_scene(scenes, 120000, 7), None)):
+        dev = pkg.create_raytracer_from_arrays(sc_big, 70, 64, 64, seed=2, flags=pkg.FLAG_TRUE_CLOSEST_HIT | pkg.FLAG_DEVICE_LBVH)
+        host = pkg.create_raytracer_from_arrays(sc_big, 70, 64, 64, seed=2, flags=pkg.FLAG_TRUE_CLOSEST_HIT)
+        di, ds, hs = dev.bvh_build_info(), dev.accel_stats(), host.accel_stats()
+        if expect_device is not None:
+            assert di["on_device"] == expect_device
+        print("\n[120k triangles, %s] device LBVH requested: on device %s, device %.2f ms, wall %.2f ms, %d nodes, depth %d | host SAH: %.1f ms, %d nodes, depth %d"
+              % (label, di["on_device"], di["device_ms"], ds["bvh_build_ms"], ds["nodes"], ds["max_depth"], hs["bvh_build_ms"], hs["nodes"], hs["max_depth"]))
+        v = np.asarray(sc_big["tri_verts"], np.float32).reshape(-1, 3); lo_, hi_ = v.min(0), v.max(0)
+        org = rng.uniform(lo_, hi_, (60000, 3)); tgt = rng.uniform(lo_, hi_, (60000, 3))
+        rays = np.concatenate([org, tgt - org], axis=1).astype(np.float32)
+        d_tuv, d_prim = dev.intersect_rays(rays); h_tuv, h_prim = host.intersect_rays(rays)
+        assert np.array_equal(d_prim, h_prim) and np.array_equal(bits(d_tuv[d_prim != 0xFFFFFFFF]), bits(h_tuv[h_prim != 0xFFFFFFFF]))
+        dev.render(1); host.render(1)
+        assert np.array_equal(bits(dev.film.pixel_datas()[0]), bits(host.film.pixel_datas()[0]))
