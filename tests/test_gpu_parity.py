@@ -731,6 +731,24 @@ def test_randomised_configurations_match_oracle(pkg, scenes, oracle):
         assert np.array_equal(rt.get_tonemapped_pixels()[m], orc.get_tonemapped_pixels()[m]), desc
 
 
+def test_pipelined_slice_schedule_is_only_a_schedule(pkg, scenes, oracle, sem, monkeypatch):
+    """MI355RT_PIPELINE=1 (the measured, not shipped schedule: every slice's trace launches on ONE stream, round by round, the
+    other launches on the slices' own streams, ordered by events) with and without a cap on the trace grid: the film and the
+    counters of 3 slices x 2 passes are the oracle's, as with the default schedule."""
+    name, w, h, spp = "thai2", 72, 52, 4
+    orc = oracle.Oracle(scenes(name), w, h, seed=8, flags=sem.orc)
+    oc = orc.render(spp, nthreads=8)
+    for blocks in ("0", "3"):
+        monkeypatch.setenv("MI355RT_PIPELINE", "1"); monkeypatch.setenv("MI355RT_PIPE_BLOCKS", blocks)
+        rt = make(pkg, scenes, name, w, h, seed=8, samples_per_pass=2, flags=sem.gpu)
+        rt.set_slices(3)
+        c = rt.render(spp)
+        assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+        gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+        assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+    monkeypatch.delenv("MI355RT_PIPELINE"); monkeypatch.delenv("MI355RT_PIPE_BLOCKS")
+
+
 # ---- device LBVH (MI355RT_FLAG_DEVICE_LBVH): a different tree, the same results ---------------------------------
 @pytest.mark.parametrize("name", ["ico2", "ico3_tex", "thai2"])
 def test_device_lbvh_gives_the_same_results(pkg, scenes, oracle, sem, name):
