@@ -9,12 +9,16 @@
 //                    mod.rs:93-98).  Persistent waves; a lane that finishes its ray is refilled from
 //                    the wave's current chunk (wave64 ballot + prefix popcount, no atomics; one atomic
 //                    per CHUNK to pull the next one), so lanes stay busy although ray lengths differ.
-//                    A radiance ray stores its hit record; a finished unblocked shadow ray stores its
-//                    light term (mod.rs:232-256).
-//   shade  round r : one wave per chunk.  Hits are compacted into an LDS index list (ballot +
-//                    prefix popcount), then shade() set-up — normal, Phong terms, shadow ray
-//                    (mod.rs:198-257) — and the level r+1 reflection rays (mod.rs:178-196) are
-//                    appended to the chunk's region of the next queue with wave-local counters.
+//                    Finished rays wait in their lanes; at the next refill a radiance ray stores its
+//                    hit record and (true-closest mode) an unblocked shadow ray its light term
+//                    (mod.rs:232-256).  A shadow ray is rebuilt from its record's hit point and the light.
+//   confirm round r: reference-default semantics only: the octree's answer derived from the true
+//                    closest hit (traverse.hpp, confirm_walk); settles the shadow rays of the round.
+//   shade  round r : one wave per chunk, chunks pulled like the trace kernel pulls them.  Hits are
+//                    compacted into an LDS index list (ballot + prefix popcount), then shade() set-up —
+//                    normal, Phong terms, shadow record (mod.rs:198-257) — and the level r+1 reflection
+//                    rays (mod.rs:178-196) are appended to the chunk's region of the next queue with
+//                    wave-local counters (32-byte records, non-temporal stores: "ray records" below).
 //   resolve        : per pixel, combine the per-node light terms in the reference's own summation
 //                    order (mod.rs:154-175) and add the samples to the film in sample order
 //                    (film.rs:20-24).
