@@ -75,9 +75,9 @@ def parse_args():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 5 if args.mode == "frame" else 2000
+        args.steps = 10 if args.mode == "frame" else 2000          # 3 warm-up frames, then >= 10 timed
     if args.warmup is None:
-        args.warmup = 2 if args.mode == "frame" else 100
+        args.warmup = 3 if args.mode == "frame" else 100
     return args
 
 
