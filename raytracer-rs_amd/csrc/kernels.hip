@@ -51,6 +51,9 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 #ifndef MI355RT_SHADE_P_BLOCKS
 #define MI355RT_SHADE_P_BLOCKS 5               // blocks per CU the shade kernels are compiled for and launched with (A/B knobs)
 #endif
+#ifndef MI355RT_SHADE_PW_BLOCKS
+#define MI355RT_SHADE_PW_BLOCKS 4              // primary shade kernel with the confirm walk inside: 128 VGPRs, no scratch (5 blocks: 80 B of scratch, 5 % slower)
+#endif
 #ifndef MI355RT_SHADE_S_BLOCKS
 #define MI355RT_SHADE_S_BLOCKS 7
 #endif
@@ -626,7 +629,10 @@ __device__ __forceinline__ void hemisphere_walk(const float4* __restrict__ table
 // ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
 // Shade the hits of one chunk (one wave): see the header of this file.
 // in_nrad: radiance rays of the chunk in in_q (ignored for PRIMARY); out_nrad / out_nshadow: what was appended to out_q.
-template <bool PRIMARY, class List>
+// WALK (primary round of the wavefront kernels, reference-default semantics): the octree confirm step of the hits is done
+// here, on the ray this kernel regenerates anyway, instead of in a confirm launch of its own; a hit the octree drops keeps
+// its (zeroed) light-term slot and is shaded no further: it resolves to black like a miss (mod.rs:99-100).
+template <bool PRIMARY, class List, bool WALK = false>
 __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level, uint32_t chunk, const List list,
                                             const float4* __restrict__ in_q, uint32_t in_nrad, uint32_t& out_nrad, uint32_t& out_nshadow,
                                             const float4* __restrict__ hits,
@@ -671,9 +677,9 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             }
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t out_front = 0u, out_back = 0u;
+        uint32_t out_front = 0u, out_back = 0u, dropped = 0u;
         for (uint32_t j = 0; j < cnt; j += 64u) {
-            const bool active = j + (uint32_t)lane < cnt;
+            bool active = j + (uint32_t)lane < cnt;
             f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), hp = mk3(0, 0, 0), n = mk3(0, 0, 1);
             uint32_t slot = 0u, node = 0u, pixel = 0u, sampleno = 0u, geom = 0u;
             float4 h = make_float4(0, 0, 0, 0);
@@ -691,6 +697,15 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                     pixel = px.x; sampleno = px.y;
                 }
                 if (PRIMARY && level < ps.recursions) ps.slot_ps[slot] = make_uint2(pixel, sampleno);   // what the deeper levels hash with
+                if (WALK) {
+                    float wt = h.x, wu = h.y, wv = h.z; uint32_t wprim = __float_as_uint(h.w);
+                    confirm_walk(sc, o, d, wt, wu, wv, wprim);
+                    h = make_float4(wt, wu, wv, __uint_as_float(wprim));
+                    active = wprim != kMiss;
+                }
+            }
+            if (WALK) dropped += (uint32_t)__popcll(__ballot(j + (uint32_t)lane < cnt && !active));
+            if (active) {
                 hp = add3(o, sscale(h.x, d));                                          // mod.rs:212
                 const float4 nn = ((const float4*)sc.normals)[__float_as_uint(h.w)];   // calc_normal, mod.rs:198-205 (precomputed)
                 n = mk3(nn.x, nn.y, nn.z);
@@ -769,7 +784,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
         if (out_front + out_back > ps.region) { if (lane == 0) counters->overflow = 1u; out_front = 0u; out_back = 0u; }
         if (lane == 0) out_counts[chunk] = make_uint2(out_front, out_back);
         out_nrad = out_front; out_nshadow = out_back;
-        acc_bounce += out_front; acc_shadow += out_back; acc_hits += cnt;
+        acc_bounce += out_front; acc_shadow += out_back; acc_hits += cnt - dropped;
     }
 }
 
@@ -784,8 +799,8 @@ __device__ __forceinline__ void flush_shade_counters(DCounters* counters, uint32
     }
 }
 
-template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock, PRIMARY ? MI355RT_SHADE_P_BLOCKS : MI355RT_SHADE_S_BLOCKS) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
+template <bool PRIMARY, bool WALK>
+__global__ __launch_bounds__(kBlock, PRIMARY ? (WALK ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : MI355RT_SHADE_S_BLOCKS) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       const float4* __restrict__ hits,
                                                       float4* __restrict__ out_q, uint2* __restrict__ out_counts, uint32_t* cursor,
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? MI355RT_SHADE_P_BLOCKS : MI355RT_
     PullState pull; uint32_t chunk = 0u;
     while (pull_chunk(cursor, ps.nchunks, kShadePullMode ? kShadePullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
         uint32_t o_rad, o_sh;
-        shade_chunk<PRIMARY>(sc, cam, ps, level, chunk, list, in_q, PRIMARY ? 0u : in_counts[chunk].x, o_rad, o_sh, hits, out_q, out_counts, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
+        shade_chunk<PRIMARY, LinearList, WALK>(sc, cam, ps, level, chunk, list, in_q, PRIMARY ? 0u : in_counts[chunk].x, o_rad, o_sh, hits, out_q, out_counts, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
     }
     flush_shade_counters(counters, wave, acc_bounce, acc_shadow, PRIMARY ? acc_hits : 0ull);
 }
@@ -1143,20 +1158,21 @@ hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, co
     return hipGetLastError();
 }
 
-hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
+hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
                         const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts, uint32_t* cursor,
                         float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters)
 {
     const size_t lds = (size_t)ps.list_cap * kWavesPerBlock * sizeof(uint32_t);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned cap = (unsigned)num_cus * (primary ? MI355RT_SHADE_P_BLOCKS : MI355RT_SHADE_S_BLOCKS);    // what the chip holds at once
+    const unsigned cap = (unsigned)num_cus * (primary ? (walk ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : MI355RT_SHADE_S_BLOCKS);    // what the chip holds at once
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(kBlock);
-    if (primary) hipLaunchKernelGGL((shade_kernel<true>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
-                                    (const float4*)hits, (float4*)out_q, (uint2*)out_counts, cursor, slot_L, sample_slot, film_n, counters);
-    else hipLaunchKernelGGL((shade_kernel<false>), grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts,
-                            (const float4*)hits, (float4*)out_q, (uint2*)out_counts, cursor, slot_L, sample_slot, film_n, counters);
+#define MI355RT_SHADE_ARGS grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts, (const float4*)hits, (float4*)out_q, (uint2*)out_counts, cursor, slot_L, sample_slot, film_n, counters
+    if (primary && walk) hipLaunchKernelGGL((shade_kernel<true, true>), MI355RT_SHADE_ARGS);
+    else if (primary) hipLaunchKernelGGL((shade_kernel<true, false>), MI355RT_SHADE_ARGS);
+    else hipLaunchKernelGGL((shade_kernel<false, false>), MI355RT_SHADE_ARGS);
+#undef MI355RT_SHADE_ARGS
     return hipGetLastError();
 }
 

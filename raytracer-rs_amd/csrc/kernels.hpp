@@ -11,7 +11,7 @@ hipError_t launch_trace(hipStream_t stream, int num_cus, int blocks_per_cu_cap, 
                         float* slot_L, const uint32_t* film_n, DCounters* counters);
 hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
                                const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n);
-hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
+hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
                         const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts, uint32_t* cursor,
                         float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters);
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,

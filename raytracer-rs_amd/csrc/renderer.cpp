@@ -545,7 +545,11 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
     if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], tst)); ev_used_ += 2; }
     ++launches_;
     if (tst != st) { HIP_TRY(hipEventRecord(sl.ev_traced, tst)); HIP_TRY(hipStreamWaitEvent(st, sl.ev_traced, 0)); }
-    if (mode_ == kModeConfirm && !dscene_.oct_single_leaf)   // true closest hits -> the reference intersector's answers; settles the shadow rays of this round (one-leaf octrees: done in the trace kernel)
+    // true closest hits -> the reference intersector's answers; settles the shadow rays of this round (one-leaf octrees: done in
+    // the trace kernel; the primary round: done by the shade kernel on the ray it regenerates anyway, MI355RT_NO_SHADE_WALK undoes that)
+    const bool confirm_here = mode_ == kModeConfirm && !dscene_.oct_single_leaf;
+    const bool shade_walks = confirm_here && r == 0 && !getenv("MI355RT_NO_SHADE_WALK");
+    if (confirm_here && !shade_walks)
         HIP_TRY(launch_confirm(st, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound + kConfirmCursorOffset, sl.d_slot_L, d_film_n_));
     if (balance_dbg) {
         DCounters c0{};
@@ -571,7 +575,7 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
                     (double)c0.t_sum_end / c0.n_waves / 100.0, (double)(c0.t_first_end - c0.t_start) / 100.0, (double)(c0.t_last_end - c0.t_start) / 100.0);
     }
     if (r <= cfg.recursions)
-        HIP_TRY(launch_shade(st, num_cus_, r == 0, dscene_, cam, ps, r, in_q, in_c, sl.d_hits, sl.d_queue[r & 1], sl.d_chunk_counts[r & 1], sl.d_ctrl + r * kCtrlWordsPerRound + kShadeCursorOffset, sl.d_slot_L, sl.d_sample_slot, d_film_n_, d_counters_));
+        HIP_TRY(launch_shade(st, num_cus_, r == 0, shade_walks, dscene_, cam, ps, r, in_q, in_c, sl.d_hits, sl.d_queue[r & 1], sl.d_chunk_counts[r & 1], sl.d_ctrl + r * kCtrlWordsPerRound + kShadeCursorOffset, sl.d_slot_L, sl.d_sample_slot, d_film_n_, d_counters_));
     return true;
 }
 
