@@ -54,6 +54,9 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 #ifndef MI355RT_SHADE_PW_BLOCKS
 #define MI355RT_SHADE_PW_BLOCKS 4              // primary shade kernel with the confirm walk inside: 128 VGPRs, no scratch (5 blocks: 80 B of scratch, 5 % slower)
 #endif
+#ifndef MI355RT_SHADE_SW_BLOCKS
+#define MI355RT_SHADE_SW_BLOCKS 5              // secondary shade kernel with the confirm walk of the radiance hits inside
+#endif
 #ifndef MI355RT_SHADE_S_BLOCKS
 #define MI355RT_SHADE_S_BLOCKS 7
 #endif
@@ -563,7 +566,7 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
 // list and walks 64 of them whenever it has 64 — across chunk borders (the writes are per record, in place).
 template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel(DScene sc, DCamera cam, DPass ps, const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
-                                                         float4* __restrict__ hits, uint32_t* cursor, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
+                                                         float4* __restrict__ hits, uint32_t* cursor, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n, uint32_t shadow_only)
 {
     __shared__ uint32_t s_list[kWavesPerBlock][2][128];   // per wave: up to 127 pending entries of { record index | shadow << 31, sample index }
     const int lane = lane_id();
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel
             if (chunk_is_culled(cam, ps, chunk, n_rad)) continue;
         } else { const uint2 n = in_counts[chunk]; n_rad = n.x; n_sh = n.y; }
         const uint32_t n_tot = n_rad + n_sh;
-        for (uint32_t it = 0; it < n_tot; it += 64u) {
+        for (uint32_t it = shadow_only ? n_rad : 0u; it < n_tot; it += 64u) {     // shadow_only: the shade kernel of the round confirms the radiance hits itself
             const uint32_t i = it + (uint32_t)lane;
             const bool valid = i < n_tot;
             const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
@@ -800,7 +803,7 @@ __device__ __forceinline__ void flush_shade_counters(DCounters* counters, uint32
 }
 
 template <bool PRIMARY, bool WALK>
-__global__ __launch_bounds__(kBlock, PRIMARY ? (WALK ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : MI355RT_SHADE_S_BLOCKS) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
+__global__ __launch_bounds__(kBlock, PRIMARY ? (WALK ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : (WALK ? MI355RT_SHADE_SW_BLOCKS : MI355RT_SHADE_S_BLOCKS)) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       const float4* __restrict__ hits,
                                                       float4* __restrict__ out_q, uint2* __restrict__ out_counts, uint32_t* cursor,
@@ -1164,13 +1167,14 @@ hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk
 {
     const size_t lds = (size_t)ps.list_cap * kWavesPerBlock * sizeof(uint32_t);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned cap = (unsigned)num_cus * (primary ? (walk ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : MI355RT_SHADE_S_BLOCKS);    // what the chip holds at once
+    const unsigned cap = (unsigned)num_cus * (primary ? (walk ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : (walk ? MI355RT_SHADE_SW_BLOCKS : MI355RT_SHADE_S_BLOCKS));    // what the chip holds at once
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(kBlock);
 #define MI355RT_SHADE_ARGS grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts, (const float4*)hits, (float4*)out_q, (uint2*)out_counts, cursor, slot_L, sample_slot, film_n, counters
     if (primary && walk) hipLaunchKernelGGL((shade_kernel<true, true>), MI355RT_SHADE_ARGS);
     else if (primary) hipLaunchKernelGGL((shade_kernel<true, false>), MI355RT_SHADE_ARGS);
+    else if (walk) hipLaunchKernelGGL((shade_kernel<false, true>), MI355RT_SHADE_ARGS);
     else hipLaunchKernelGGL((shade_kernel<false, false>), MI355RT_SHADE_ARGS);
 #undef MI355RT_SHADE_ARGS
     return hipGetLastError();
@@ -1241,7 +1245,7 @@ hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, cons
 }
 
 // the octree confirm step of one round (reference-default semantics), between its trace and its shade launch
-hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
+hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, bool shadow_only, const DScene& sc, const DCamera& cam, const DPass& ps,
                           const void* in_q, const void* in_counts, void* hits, uint32_t* cursor, float* slot_L, const uint32_t* film_n)
 {
     const size_t lds = 0;                                  // the pending lists are static LDS (128 entries per wave)
@@ -1249,8 +1253,8 @@ hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const D
     const unsigned cap = (unsigned)num_cus * MI355RT_CONFIRM_BLOCKS;   // several chunks per wave, so that batches fill up across chunks
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    if (primary) hipLaunchKernelGGL(confirm_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n);
-    else hipLaunchKernelGGL(confirm_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n);
+    if (primary) hipLaunchKernelGGL(confirm_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n, 0u);
+    else hipLaunchKernelGGL(confirm_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n, shadow_only ? 1u : 0u);
     return hipGetLastError();
 }
 

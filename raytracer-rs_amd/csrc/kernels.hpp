@@ -19,7 +19,7 @@ hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, u
 // one 50-row frame (1 sample per pixel) in a single launch: every wave takes a 64-sample chunk through all rounds
 uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes, uint32_t records_per_sample);
 // reference-default semantics: true closest hits of a round -> the octree intersector's answers (+ the shadow predicate)
-hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
+hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, bool shadow_only, const DScene& sc, const DCamera& cam, const DPass& ps,
                           const void* in_q, const void* in_counts, void* hits, uint32_t* cursor, float* slot_L, const uint32_t* film_n);
 hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes, uint32_t records_per_sample,
                              void* q0, void* q1, void* c0, void* c1, void* hits, float* slot_L, uint32_t* sample_slot,
