@@ -848,8 +848,11 @@ __device__ f3 node_radiance(const float* __restrict__ L, const DPass& ps, uint32
 // j + kResolveLanes, ... (the loads), then the values of one round are exchanged inside the wave and every
 // lane of the group ADDS them in sample order (bit-exactness) — redundantly, so there is no divergence.
 // With one thread per pixel, a pass with few pixels and many samples per pixel (one rank's stripes of an
-// 8-GPU frame: 512 spp) is a latency-bound loop of dependent loads on a nearly empty chip.
-constexpr uint32_t kResolveLanes = 8u;
+// 8-GPU frame: 512 spp) is a latency-bound loop of dependent loads on a nearly empty chip; with many lanes per
+// pixel and few samples most lanes of a group have nothing to load.  The launcher picks the group size from
+// the samples per pixel of the pass (21-spp passes of a 1080p frame: 1 / 2 / 4 / 8 / 16 lanes -> 0.22 / 0.21 /
+// 0.25 / 0.31 / 0.55 ms).
+template <uint32_t kResolveLanes>
 __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, uint32_t nlights, const float* __restrict__ slot_L,
                                                      const uint32_t* __restrict__ sample_slot,
                                                      float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
@@ -1183,8 +1186,19 @@ hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
 {
-    dim3 block(256), grid((unsigned)(((size_t)ps.npix * kResolveLanes + 255) / 256));
-    hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, ps, width, nlights, slot_L, sample_slot, film_sum, film_sumsq, film_n, debug_color);
+    const uint32_t spp = ps.npix ? ps.nsamples / ps.npix : 1u;
+    uint32_t lanes = spp <= 32u ? 2u : (spp <= 96u ? 4u : 8u);
+    if (const char* e = getenv("MI355RT_RESOLVE_LANES")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) lanes = (uint32_t)v; }
+    dim3 block(256), grid((unsigned)(((size_t)ps.npix * lanes + 255) / 256));
+#define MI355RT_RESOLVE_ARGS grid, block, 0, stream, ps, width, nlights, slot_L, sample_slot, film_sum, film_sumsq, film_n, debug_color
+    switch (lanes) {
+        case 1: hipLaunchKernelGGL(resolve_kernel<1>, MI355RT_RESOLVE_ARGS); break;
+        case 2: hipLaunchKernelGGL(resolve_kernel<2>, MI355RT_RESOLVE_ARGS); break;
+        case 4: hipLaunchKernelGGL(resolve_kernel<4>, MI355RT_RESOLVE_ARGS); break;
+        case 16: hipLaunchKernelGGL(resolve_kernel<16>, MI355RT_RESOLVE_ARGS); break;
+        default: hipLaunchKernelGGL(resolve_kernel<8>, MI355RT_RESOLVE_ARGS); break;
+    }
+#undef MI355RT_RESOLVE_ARGS
     return hipGetLastError();
 }
 
