@@ -575,7 +575,7 @@ def test_headless_cli_renders_the_library_frame(pkg, scenes, tmp_path):
     exe = os.path.join(root, "raytracer-rs_amd", "bin", "raytracer")
     scene = os.path.join(GOLDEN, "scenes", "ico2.scene")
     w, h = 96, 70
-    for extra, frames in ((["-i", "2"], None), (["--spp", "3"], 3)):
+    for extra, frames in ((["-i", "2"], None), (["--spp", "3"], 3), (["--spp", "3", "--device-lbvh"], 3)):     # the device-built BVH: same picture
         out = str(tmp_path / "o.ppm")
         r = subprocess.run([exe, "-f", scene, "--width", str(w), "--height", str(h), "--seed", "4", "--out", out] + extra,
                            capture_output=True, text=True, timeout=120)
