@@ -250,7 +250,11 @@ def main():
     if world > 1 and args.native_gather != "off":
         try:
             native = stripes.NativeGather(pkg, rt, dist, rank, world)
-            gather_kind = "library RCCL (mi355rt_comm_*: grouped ncclSend/ncclRecv of the u32 stripes to rank 0 + broadcast-free placement)"
+            rt.film.clear(); rt.render(1)                             # one cheap frame through both transports before anything is timed
+            if not native.verify_against(dist, rank, fg, stripe):
+                native.close(); native = None
+                raise RuntimeError("the library's RCCL gather did not reproduce the all_gather frame")
+            gather_kind = "library RCCL (mi355rt_comm_*: grouped ncclSend/ncclRecv of the u32 stripes to rank 0 + broadcast-free placement; checked against all_gather on one frame)"
         except Exception as e:                                    # noqa: BLE001 — fall back to torch.distributed, say so in the line
             if args.native_gather == "on":
                 raise

@@ -72,6 +72,23 @@ class NativeGather:
     def gather(self):
         self.rt.comm_gather_frame(0, None)          # queued on the handle's stream; rt.synchronize() waits for it
 
+    def verify_against(self, dist, rank, frame_gather, stripe):
+        """One frame through BOTH transports (collective: every rank calls it): the library's RCCL gather must put on rank 0
+        exactly the frame torch.distributed's all_gather assembles.  Returns the verdict agreed on by all ranks."""
+        import numpy as np
+        rt = self.rt
+        out = np.zeros(frame_gather.height * frame_gather.width, np.uint32) if rank == 0 else None
+        rt.comm_gather_frame(0, out if rank == 0 else None)
+        rt.synchronize()
+        rt.tonemap_owned_rows_device(stripe.data_ptr(), len(rt.owned_rows()) * frame_gather.width)
+        ref = frame_gather.gather(dist, stripe)
+        ok = 1
+        if rank == 0:
+            ok = int(np.array_equal(out, ref.cpu().numpy().view(np.uint32)))
+        flag = torch.tensor([ok], dtype=torch.int32, device=stripe.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag[0]))
+
     def close(self):
         self.rt.synchronize()
         self.rt.comm_destroy()

@@ -92,6 +92,31 @@ def test_rccl_communicator_path_world_of_one(pkg, scenes):
         rt.comm_gather_frame(0, out)
 
 
+def test_native_gather_wrapper_and_its_check_world_of_one(pkg, scenes):
+    """stripes.NativeGather (what bench.py uses for N > 1: RCCL id handed round with torch.distributed, communicator per
+    rank) and verify_against (one frame through the library's gather AND torch's all_gather, compared on rank 0) with a
+    process group of one rank: the code the N > 1 bench runs before anything is timed."""
+    import importlib
+    import socket
+    import torch
+    import torch.distributed as dist
+    stripes = importlib.import_module("raytracer_rs_amd.stripes")
+    name, w, h = "ico2", 96, 64
+    rt = make(pkg, scenes, name, w, h, seed=3, stripe_rows=8)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        native = stripes.NativeGather(pkg, rt, dist, 0, 1)
+        fg = stripes.FrameGather(h, w, 8, 1, "cuda")
+        stripe = fg.stripe_buffer("cuda")
+        rt.render(2)
+        assert native.verify_against(dist, 0, fg, stripe)
+        native.gather(); rt.synchronize()
+        native.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_cli_gpus_and_png(pkg, scenes, tmp_path):
     """bin/raytracer --gpus 3 (a device group; --share-device puts it on the one GPU here) writes the same picture as
     one GPU, as PPM and as PNG (decoded with Pillow)."""
