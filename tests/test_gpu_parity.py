@@ -693,9 +693,9 @@ def test_randomised_configurations_match_oracle(pkg, scenes, oracle):
     """24 random configurations — scene, image size, seed, camera pose, samples, recursion / spread, octree leaf size,
     semantics, stripes, row-index fix, whole frames mixed with 50-row frames — each compared with the oracle bit for bit
     (film sums, sums of squares, counts, packed pixels).  A fixed generator seed keeps the test reproducible."""
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(int(os.environ.get("MI355RT_TEST_RANDOM_SEED", "20261004")))
     names = ["4boxes", "ico2", "ico3_tex", "thai2"]
-    for case in range(24):
+    for case in range(int(os.environ.get("MI355RT_TEST_RANDOM_CASES", "24"))):      # soak runs: more cases, other seeds
         name = names[int(rng.integers(0, 4))]
         w, h = int(rng.integers(17, 140)), int(rng.integers(9, 110))
         seed = int(rng.integers(1, 1 << 30))
@@ -704,7 +704,8 @@ def test_randomised_configurations_match_oracle(pkg, scenes, oracle):
         closest = bool(rng.integers(0, 3) == 0)
         fix = bool(rng.integers(0, 2))
         world = int(rng.choice([1, 1, 2, 3])); rank = int(rng.integers(0, world)); srows = int(rng.choice([1, 4, 8]))
-        gflags = (pkg.FLAG_TRUE_CLOSEST_HIT if closest else 0) | (pkg.FLAG_FIX_ROW_INDEX if fix else 0)
+        lbvh = bool(rng.integers(0, 4) == 0)
+        gflags = (pkg.FLAG_TRUE_CLOSEST_HIT if closest else 0) | (pkg.FLAG_FIX_ROW_INDEX if fix else 0) | (pkg.FLAG_DEVICE_LBVH if lbvh else 0)
         oflags = (oracle.FLAG_BRUTE_FORCE if closest else 0) | (oracle.FLAG_FIX_ROW_INDEX if fix else 0)
         rt = pkg.create_raytracer_from_arrays(scenes(name), tpl, w, h, seed=seed, recursions=rec, spread=spread, flags=gflags,
                                               stripe_rows=srows, stripe_rank=rank, stripe_world=world)
@@ -715,7 +716,7 @@ def test_randomised_configurations_match_oracle(pkg, scenes, oracle):
             rt.camera.add_x_angle(float(ax)); orc.camera_add_x_angle(float(ax))
             rt.camera.add_y_angle(float(ay)); orc.camera_add_y_angle(float(ay))
         rows = rt.owned_rows()
-        desc = (case, name, w, h, seed, rec, spread, tpl, closest, fix, world, rank, srows)
+        desc = (case, name, w, h, seed, rec, spread, tpl, closest, fix, world, rank, srows, lbvh)
         for step in range(int(rng.integers(1, 4))):
             if world == 1 and rng.integers(0, 2) == 0:
                 assert rt.trace_frame_additive() == orc.trace_frame_additive(), desc      # the oracle has no stripes: frames only on whole handles
