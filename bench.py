@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 SCENE = "thai2"
 WIDTH, HEIGHT, SPP = 1920, 1080, 64
-STRIPE_ROWS = 8
+STRIPE_ROWS = 8                 # rows per stripe (--stripe-rows)
 HBM_PEAK_GBS = 8000.0
 NUM_SIMDS = 1024            # 256 CUs x 4
 NUM_SE = 32                 # 8 XCDs x 4 shader engines: SQ_BUSY_CYCLES is summed over them
@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline PMC fields become null)")
     ap.add_argument("--native-gather", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: gather the stripes with the library's own RCCL path (on), torch.distributed (off), or try native first")
+    ap.add_argument("--stripe-rows", type=int, default=0, help="rows per stripe of the deal over ranks (and of the blocks dealt to the frame slices); 0: the default")
     ap.add_argument("--device-lbvh", action="store_true", help="MI355RT_FLAG_DEVICE_LBVH: BVH built on the device (Morton order) instead of the host's SAH build")
     ap.add_argument("--true-closest-hit", action="store_true",
                     help="MI355RT_FLAG_TRUE_CLOSEST_HIT: NoAccelerationIntersector semantics (no octree confirm step) instead of the reference's default intersector")
@@ -74,6 +75,9 @@ def parse_args():
     ap.add_argument("--slices", type=int, default=0, help="concurrent frame slices of the timed frames (0: library default)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.stripe_rows > 0:
+        global STRIPE_ROWS
+        STRIPE_ROWS = args.stripe_rows
     if args.steps is None:
         args.steps = 10 if args.mode == "frame" else 2000          # 3 warm-up frames, then >= 10 timed
     if args.warmup is None:

@@ -14,7 +14,7 @@ sc = sio.load_scene_file(os.path.join(ge.SCENES, "thai2.scene"))
 def probe(label, w, h, spp_of, worlds):
     base = None
     for world in worlds:
-        rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=1, stripe_rows=8, stripe_rank=0, stripe_world=world)
+        rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=1, stripe_rows=int(os.environ.get("PROBE_STRIPE_ROWS", "8")), stripe_rank=0, stripe_world=world)
         spp = spp_of(world)
         best = 1e9
         for it in range(4):
