@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 SCENE = "thai2"
 WIDTH, HEIGHT, SPP = 1920, 1080, 64
-STRIPE_ROWS = 8                 # rows per stripe (--stripe-rows)
+STRIPE_ROWS = 2                 # rows per stripe of the deal over ranks and slices (--stripe-rows); measured: profiles/r02_notes.md
 HBM_PEAK_GBS = 8000.0
 NUM_SIMDS = 1024            # 256 CUs x 4
 NUM_SE = 32                 # 8 XCDs x 4 shader engines: SQ_BUSY_CYCLES is summed over them
@@ -470,7 +470,8 @@ def dropin_mode(args, ge, pkg, scene, pmc, pmc_note):
     import numpy as np
     import torch
     w, h = 1024, 768
-    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, seed=1)
+    extra = {"stripe_rows": args.stripe_rows} if args.stripe_rows > 0 else {}
+    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, seed=1, **extra)
     buf = np.empty(w * h, np.uint32)
 
     def step():

@@ -109,7 +109,8 @@ typedef struct mi355rt_config {
     int32_t device;                  /* HIP device ordinal */
     /* Row-stripe ownership for multi-GPU rendering: this handle renders the stripes of
      * `stripe_rows` rows whose index is congruent to stripe_rank modulo stripe_world.
-     * stripe_world <= 1 renders every row. */
+     * stripe_world <= 1 renders every row.  mi355rt_default_config sets stripe_rows = 4: thin stripes balance the ranks (the
+     * slowest rank sets the frame), and the pixel tiles of a pass are cut to the stripe height, so they cost nothing per ray. */
     uint32_t stripe_rows, stripe_rank, stripe_world;
     uint32_t samples_per_pass;       /* samples per pixel traced per wavefront pass (0 = auto) */
     /* Device group: the handle drives `device_count` HIP devices of THIS process (device, device + 1, ...).  Rows

@@ -44,7 +44,7 @@ void mi355rt_default_config(mi355rt_config* cfg)
     cfg->triangles_per_leaf = MI355RT_DEFAULT_TRIANGLES_PER_LEAF;
     cfg->recursions = 2; cfg->spread = 1;                         // mod.rs:81-82
     cfg->seed = 1; cfg->device = 0;
-    cfg->stripe_rows = 8; cfg->stripe_rank = 0; cfg->stripe_world = 1;
+    cfg->stripe_rows = 4; cfg->stripe_rank = 0; cfg->stripe_world = 1;     // 4-row stripes: measured against 8 / 2 / 1 (profiles/r02_notes.md)
     cfg->device_count = 1;
 }
 

@@ -69,6 +69,7 @@ struct DPass {
     uint32_t row0;
     uint32_t row_wrap;        // entries of the cyclic row list (50-row frames: rows[(row0 + i) % row_wrap]); 0xFFFFFFFF: no wrap
     uint32_t npix;            // pixels in this pass (rows_in_pass * width)
+    uint32_t row_group, row_group_shift;   // rows per pixel-tile group of the pass order (a power of two <= 8) and its log2
     uint32_t nsamples;        // npix * samples per pixel in this pass
     uint32_t seed;
     uint32_t flags;

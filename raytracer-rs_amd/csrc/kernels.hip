@@ -172,21 +172,22 @@ __device__ __forceinline__ f3 fetch_texel(const DScene& sc, uint32_t tex, float 
     return mk3(p[0], p[1], p[2]);
 }
 
-// Pass order of the pixels.  The rows of a pass are taken in groups of kRowGroup and walked column by column
+// Pass order of the pixels.  The rows of a pass are taken in groups of ps.row_group (8) and walked column by column
 // inside a group, so that 64 consecutive samples are an 8x8 pixel tile and a chunk of 256 a 32x8 one: the
 // primary rays of a wave are as coherent as they can be, and the chunk culling below tests compact tiles.
 // (The film does not depend on the order: every pixel accumulates its own samples in sample order.)
-constexpr uint32_t kRowGroup = 8u;
+// (ps.row_group: 8 rows, or the stripe height when the rows are dealt in stripes of fewer rows — a group never spans two stripes)
 // entry i of the pass's row list; the list is a cyclic window of ps.row_wrap entries when the pass is a 50-row
 // frame of trace_frame_additive (its rows are a run of the handle's device-resident owned-row list that may wrap)
 __device__ __forceinline__ uint32_t pass_row(const DPass& ps, uint32_t i) { return ps.rows[i >= ps.row_wrap ? i - ps.row_wrap : i]; }
 __device__ __forceinline__ void pass_column(const DPass& ps, uint32_t width, uint32_t p, uint32_t& first_row, uint32_t& nrows_in_group, uint32_t& x, uint32_t& y)
 {
-    const uint32_t gs = width * kRowGroup, g = p / gs, q = p - g * gs;
-    nrows_in_group = min(kRowGroup, ps.npix / width - g * kRowGroup);
-    x = nrows_in_group == kRowGroup ? q / kRowGroup : q / nrows_in_group;
+    const uint32_t rg = ps.row_group;                               // a power of two
+    const uint32_t gs = width * rg, g = p / gs, q = p - g * gs;
+    nrows_in_group = min(rg, ps.npix / width - g * rg);
+    x = nrows_in_group == rg ? q >> ps.row_group_shift : q / nrows_in_group;
     y = q - x * nrows_in_group;
-    first_row = ps.row0 + g * kRowGroup;
+    first_row = ps.row0 + g * rg;
 }
 __device__ __forceinline__ uint32_t pass_pixel(const DPass& ps, uint32_t width, uint32_t p)
 {

@@ -476,6 +476,10 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
 {
     ps = DPass{};
     ps.rows = d_rows; ps.row0 = row0; ps.row_wrap = row_wrap; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
+    // tile groups of 8 rows, or of the stripe height when rows are dealt (to ranks and to slices) in blocks of fewer rows: a group
+    // that spans two blocks lying far apart in the image makes loose culling rectangles and incoherent tiles
+    ps.row_group_shift = 3; while (ps.row_group_shift > 0 && (1u << ps.row_group_shift) > cfg.stripe_rows) --ps.row_group_shift;
+    ps.row_group = 1u << ps.row_group_shift;
     ps.seed = (uint32_t)cfg.seed; ps.flags = cfg.flags; ps.recursions = cfg.recursions; ps.spread = cfg.spread;
     ps.nodes_per_sample = nodes_per_sample;
     ps.nslots = (uint32_t)((nsamples + chunk - 1) / chunk) * chunk;

@@ -1,5 +1,5 @@
 """One rank's share of an N-GPU frame, rendered on ONE GPU (no gather): what each rank of `bench.py --gpus N` does per step.
-weak:   thai2 1920x1080, stripes of rank 0 of N, 64*N spp (the same number of samples as the N=1 frame)
+weak:   thai2 1920x1080, stripes of rank 0 of N (2-row stripes like bench.py; PROBE_STRIPE_ROWS), 64*N spp (the same number of samples as the N=1 frame)
 strong: thai2 1920x1080x64 spp and 3840x2160x256 spp (BASELINE config 5) dealt to N ranks: rank 0's rows at the full spp
 The slowest rank sets the frame time; rank 0 always owns the first stripe, i.e. the largest share when the stripes do not divide evenly."""
 import os, sys, time
@@ -14,7 +14,7 @@ sc = sio.load_scene_file(os.path.join(ge.SCENES, "thai2.scene"))
 def probe(label, w, h, spp_of, worlds):
     base = None
     for world in worlds:
-        rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=1, stripe_rows=int(os.environ.get("PROBE_STRIPE_ROWS", "8")), stripe_rank=0, stripe_world=world)
+        rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=1, stripe_rows=int(os.environ.get("PROBE_STRIPE_ROWS", "2")), stripe_rank=0, stripe_world=world)
         spp = spp_of(world)
         best = 1e9
         for it in range(4):
