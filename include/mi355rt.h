@@ -32,6 +32,8 @@ extern "C" {
 
 /* DEFAULT_TRIANGLES_PER_LEAF, oct_tree_intersector.rs:12 / lib.rs:7 */
 #define MI355RT_DEFAULT_TRIANGLES_PER_LEAF 70u
+/* rows per stripe of the deal over ranks / devices / frame slices when config.stripe_rows is 0 (and what mi355rt_default_config sets) */
+#define MI355RT_DEFAULT_STRIPE_ROWS 4u
 
 /* Config.flags */
 #define MI355RT_FLAG_FIX_ROW_INDEX  1u  /* v = idx / width instead of the reference's idx / height (mod.rs:93-96) */
@@ -248,6 +250,12 @@ int mi355rt_bvh_build_info(const mi355rt_handle* h, uint32_t out[2]);
 int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8]);
 /* devices of the handle's group (1 for an ordinary handle) */
 uint32_t mi355rt_device_count(const mi355rt_handle* h);
+/* test hook: with MI355RT_DEBUG_GUARD set in the environment every pass buffer is allocated with a 256-byte tail of 0xA5;
+ * this returns how many of those bytes a launch has overwritten (0 = nothing wrote past a buffer; -1: error) */
+int64_t mi355rt_debug_check_guards(mi355rt_handle* h);
+/* device memory (HBM) the handle holds right now, summed over its devices: scene + acceleration structures + film + the
+ * pass buffers of the largest pass rendered so far + gather slots */
+uint64_t mi355rt_hbm_allocated_bytes(const mi355rt_handle* h);
 /* wait until everything queued on the handle (50-row frames, gathers) has finished on its device(s) */
 int mi355rt_synchronize(mi355rt_handle* h);
 
@@ -264,6 +272,9 @@ int mi355rt_comm_unique_id(uint8_t* id128);
 int mi355rt_comm_init(mi355rt_handle* h, const uint8_t* id128);
 int mi355rt_comm_gather_frame(mi355rt_handle* h, uint32_t root, uint32_t* host_out, size_t n);
 int mi355rt_comm_destroy(mi355rt_handle* h);
+/* ranks of the handle's live communicator as RCCL counts them (ncclCommCount; 0: no communicator, or it is not the one
+ * this handle's stripe_rank was dealt into) */
+uint32_t mi355rt_comm_ranks(mi355rt_handle* h);
 
 uint32_t mi355rt_width(const mi355rt_handle* h);
 uint32_t mi355rt_height(const mi355rt_handle* h);

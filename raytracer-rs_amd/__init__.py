@@ -136,6 +136,9 @@ ABI = [
     ("mi355rt_comm_init", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("mi355rt_comm_gather_frame", C.c_int, [_H, C.c_uint32, _U, C.c_size_t]),
     ("mi355rt_comm_destroy", C.c_int, [_H]),
+    ("mi355rt_comm_ranks", C.c_uint32, [_H]),
+    ("mi355rt_hbm_allocated_bytes", C.c_uint64, [_H]),
+    ("mi355rt_debug_check_guards", C.c_int64, [_H]),
     ("mi355rt_width", C.c_uint32, [_H]),
     ("mi355rt_height", C.c_uint32, [_H]),
     ("mi355rt_triangle_count", C.c_uint32, [_H]),
@@ -320,6 +323,18 @@ class RayTracer:
 
     def comm_destroy(self):
         self._check(lib().mi355rt_comm_destroy(self._h))
+
+    def comm_ranks(self):
+        """ranks of the live RCCL communicator as RCCL counts them (ncclCommCount); 0 without one"""
+        return int(lib().mi355rt_comm_ranks(self._h))
+
+    def debug_check_guards(self):
+        """MI355RT_DEBUG_GUARD: overwritten guard bytes behind the pass buffers (0 = clean)"""
+        return int(lib().mi355rt_debug_check_guards(self._h))
+
+    def hbm_allocated_bytes(self):
+        """device memory the handle holds right now (scene, film, pass buffers, gather slots)"""
+        return int(lib().mi355rt_hbm_allocated_bytes(self._h))
 
     def owned_rows(self):
         n = lib().mi355rt_owned_rows(self._h)

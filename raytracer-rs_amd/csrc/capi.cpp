@@ -44,7 +44,7 @@ void mi355rt_default_config(mi355rt_config* cfg)
     cfg->triangles_per_leaf = MI355RT_DEFAULT_TRIANGLES_PER_LEAF;
     cfg->recursions = 2; cfg->spread = 1;                         // mod.rs:81-82
     cfg->seed = 1; cfg->device = 0;
-    cfg->stripe_rows = 4; cfg->stripe_rank = 0; cfg->stripe_world = 1;     // 4-row stripes: measured against 8 / 2 / 1 (profiles/r02_notes.md)
+    cfg->stripe_rows = MI355RT_DEFAULT_STRIPE_ROWS; cfg->stripe_rank = 0; cfg->stripe_world = 1;     // 4-row stripes: measured against 8 / 2 / 1 (profiles/r02_notes.md)
     cfg->device_count = 1;
 }
 
@@ -295,6 +295,22 @@ int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8])
 }
 uint32_t mi355rt_device_count(const mi355rt_handle* h) { return h ? (uint32_t)h->g->size() : 0u; }
 
+int64_t mi355rt_debug_check_guards(mi355rt_handle* h)
+{
+    if (!h) return -1;
+    int64_t bad = 0;
+    for (size_t i = 0; i < h->g->size(); ++i) { const long b = h->g->device(i)->check_guards(); if (b < 0) return -1; bad += b; }
+    return bad;
+}
+
+uint64_t mi355rt_hbm_allocated_bytes(const mi355rt_handle* h)
+{
+    if (!h) return 0;
+    uint64_t b = 0;
+    for (size_t i = 0; i < h->g->size(); ++i) b += h->g->device(i)->hbm_allocated_bytes();
+    return b;
+}
+
 int mi355rt_synchronize(mi355rt_handle* h)
 {
     if (!h) return MI355RT_E_INVALID;
@@ -325,6 +341,7 @@ int mi355rt_comm_destroy(mi355rt_handle* h)
     h->r->comm_destroy();
     return MI355RT_OK;
 }
+uint32_t mi355rt_comm_ranks(mi355rt_handle* h) { return h ? h->r->comm_ranks() : 0u; }
 
 uint32_t mi355rt_width(const mi355rt_handle* h) { return h ? h->r->cfg.width : 0u; }
 uint32_t mi355rt_height(const mi355rt_handle* h) { return h ? h->r->cfg.height : 0u; }

@@ -20,6 +20,8 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -42,6 +44,8 @@ RcclApi* rccl()
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+        api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
         api.Send = (decltype(api.Send))sym("ncclSend");
         api.Recv = (decltype(api.Recv))sym("ncclRecv");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
@@ -80,6 +84,17 @@ bool Renderer::comm_init(const uint8_t* id128)
     return true;
 }
 
+// ranks of the communicator as RCCL itself counts them (0: none) — what bench.py reports as `rccl_ranks`
+uint32_t Renderer::comm_ranks()
+{
+    if (!comm_) return 0u;
+    RcclApi* a = rccl();
+    int n = 0, me = -1;
+    if (!a->CommCount || a->CommCount((ncclComm_t)comm_, &n) != ncclSuccess || n < 0) return 0u;
+    if (a->CommUserRank && a->CommUserRank((ncclComm_t)comm_, &me) == ncclSuccess && me != (int)cfg.stripe_rank) return 0u;   // not the communicator this handle was dealt into
+    return (uint32_t)n;
+}
+
 void Renderer::comm_destroy()
 {
     if (!comm_) return;
@@ -102,18 +117,27 @@ bool Renderer::comm_gather(uint32_t root, uint32_t* host_out, size_t n)
     const bool is_root = cfg.stripe_rank == root;
     if (!gather_prepare(is_root)) return false;
     if (!tonemap_to_gather_slot()) return false;
+    // Inside GroupStart .. GroupEnd nothing may return early: a group left open makes every later RCCL call of this thread
+    // part of it.  The first failing Send / Recv is remembered, the group is closed regardless, and a communicator whose
+    // GroupEnd fails is destroyed (its state is undefined) so that the caller gets a clean "no communicator" next time.
     RCCL_TRY(a->GroupStart());
+    ncclResult_t first = ncclSuccess; const char* what = "";
     if (is_root) {
-        for (uint32_t r = 0; r < cfg.stripe_world; ++r) {
+        for (uint32_t r = 0; r < cfg.stripe_world && first == ncclSuccess; ++r) {
             if (r == root) continue;
             const size_t count = (size_t)rows_of_rank(r) * cfg.width;
-            if (count) RCCL_TRY(a->Recv(gather_slot(r), count, ncclUint32, (int)r, (ncclComm_t)comm_, stream_));
+            if (count) { first = a->Recv(gather_slot(r), count, ncclUint32, (int)r, (ncclComm_t)comm_, stream_); what = "ncclRecv"; }
         }
     } else {
         const size_t count = owned_rows.size() * (size_t)cfg.width;
-        if (count) RCCL_TRY(a->Send(gather_slot(cfg.stripe_rank), count, ncclUint32, (int)root, (ncclComm_t)comm_, stream_));
+        if (count) { first = a->Send(gather_slot(cfg.stripe_rank), count, ncclUint32, (int)root, (ncclComm_t)comm_, stream_); what = "ncclSend"; }
     }
-    RCCL_TRY(a->GroupEnd());
+    const ncclResult_t end = a->GroupEnd();
+    if (first != ncclSuccess || end != ncclSuccess) {
+        last_error = first != ncclSuccess ? std::string(what) + ": " + a->GetErrorString(first) : std::string("ncclGroupEnd: ") + a->GetErrorString(end);
+        if (end != ncclSuccess) comm_destroy();
+        return false;
+    }
     if (is_root) return finish_gather(host_out, n);
     return true;
 }

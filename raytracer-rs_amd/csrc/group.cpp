@@ -19,7 +19,7 @@ std::unique_ptr<DeviceGroup> DeviceGroup::create(const SceneData& scene, const m
         c.device_count = 1;
         if (n > 1) {
             c.device = (cfg.flags & MI355RT_FLAG_GROUP_SHARES_DEVICE) ? cfg.device : cfg.device + (int32_t)i;
-            if (c.stripe_rows == 0) c.stripe_rows = 8;
+            if (c.stripe_rows == 0) c.stripe_rows = MI355RT_DEFAULT_STRIPE_ROWS;
             c.stripe_rank = i; c.stripe_world = n;
         }
         std::unique_ptr<Renderer> r = Renderer::create(scene, c, err, code);

@@ -32,6 +32,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "device_math.hpp"
 #include "device_types.hpp"
 #include "kernels.hpp"
@@ -786,7 +789,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
         }
         __builtin_amdgcn_wave_barrier();
         if (out_front + out_back > ps.region) { if (lane == 0) counters->overflow = 1u; out_front = 0u; out_back = 0u; }
-        if (lane == 0) out_counts[chunk] = make_uint2(out_front, out_back);
+        if (out_counts != nullptr && lane == 0) out_counts[chunk] = make_uint2(out_front, out_back);     // fused launch: null, the counts travel in registers
         out_nrad = out_front; out_nshadow = out_back;
         acc_bounce += out_front; acc_shadow += out_back; acc_hits += cnt - dropped;
     }
@@ -945,7 +948,7 @@ __device__ __forceinline__ void resolve_chunk_1spp(const DPass& ps, uint32_t wid
 }
 
 template <bool CONFIRM>
-__global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera cam, DPass ps, float4* q0, float4* q1, uint2* c0, uint2* c1,
+__global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera cam, DPass ps, float4* q0, float4* q1,
                                                             float4* hits, float* slot_L, uint32_t* sample_slot,
                                                             float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters)
 {
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera c
         trace_wave<true, false, true, true>(sc, cam, ps, nullptr, nullptr, hits, nullptr, slot_L, film_n, counters, stack, chunk, 0u, 0u);
         phase_fence();
         if (CONFIRM && !sc.oct_single_leaf) { confirm_chunk<true>(sc, cam, ps, chunk, list, nullptr, 0u, 0u, hits, slot_L, film_n); phase_fence(); }
-        shade_chunk<true>(sc, cam, ps, 0u, chunk, list, nullptr, 0u, n_rad, n_sh, hits, q0, c0, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
+        shade_chunk<true>(sc, cam, ps, 0u, chunk, list, nullptr, 0u, n_rad, n_sh, hits, q0, nullptr, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
         phase_fence();
         for (uint32_t r = 1; r < ps.recursions + 2u; ++r) {
             float4* in_q = (r - 1u) & 1u ? q1 : q0;
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera c
             if (r <= ps.recursions) {
                 unsigned long long unused = 0;
                 uint32_t o_rad = 0u, o_sh = 0u;
-                shade_chunk<false>(sc, cam, ps, r, chunk, list, in_q, n_rad, o_rad, o_sh, hits, r & 1u ? q1 : q0, r & 1u ? c1 : c0, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, unused);
+                shade_chunk<false>(sc, cam, ps, r, chunk, list, in_q, n_rad, o_rad, o_sh, hits, r & 1u ? q1 : q0, nullptr, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, unused);
                 n_rad = o_rad; n_sh = o_sh;
                 phase_fence();
             }
@@ -1112,16 +1115,20 @@ static size_t stack_bytes(uint32_t depth) { return (size_t)((depth ? depth : 1u)
 template <bool P, bool C, bool F>
 static int trace_blocks_per_cu(size_t lds)
 {
-    // the occupancy query costs ~0.3 ms of host time: ask once per (kernel, LDS size)
-    static size_t cached_lds = ~(size_t)0;
-    static int cached_nb = 0;
-    if (cached_lds != lds) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<P, C, F>, kBlock, lds) != hipSuccess || nb < 1) nb = 1;
-        cached_nb = nb > 8 ? 8 : nb;
-        cached_lds = lds;
-    }
-    return cached_nb;
+    // the occupancy query costs ~0.3 ms of host time: ask once per (kernel, device, LDS size).  Device groups launch from one
+    // host thread per device, so the cache is guarded.
+    static std::mutex mu;
+    static std::map<std::pair<int, size_t>, int> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({ dev, lds });
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<P, C, F>, kBlock, lds) != hipSuccess || nb < 1) nb = 1;
+    nb = nb > 8 ? 8 : nb;
+    cache[{ dev, lds }] = nb;
+    return nb;
 }
 
 template <bool P, bool C, bool F>
@@ -1244,17 +1251,18 @@ uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes, uin
 }
 
 hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes, uint32_t records_per_sample,
-                             void* q0, void* q1, void* c0, void* c1, void* hits, float* slot_L, uint32_t* sample_slot,
+                             void* q0, void* q1, void* hits, float* slot_L, uint32_t* sample_slot,
                              float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters)
 {
     if (ps.nchunks == 0) return hipSuccess;
+    if (ps.chunk > 64u) return hipErrorInvalidValue;          // the LDS lists hold one row of 64 entries per record of a sample
     const size_t lds = (size_t)fused_pass_lds_rows(ps.stack_depth, max_level_nodes, records_per_sample) * kBlock * sizeof(int);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned cap = (unsigned)num_cus * 8u;
     if (blocks > cap) blocks = cap;
-    if (confirm) hipLaunchKernelGGL(fused_pass_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1, (uint2*)c0, (uint2*)c1,
+    if (confirm) hipLaunchKernelGGL(fused_pass_kernel<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1,
                                     (float4*)hits, slot_L, sample_slot, film_sum, film_sumsq, film_n, counters);
-    else hipLaunchKernelGGL(fused_pass_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1, (uint2*)c0, (uint2*)c1,
+    else hipLaunchKernelGGL(fused_pass_kernel<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, cam, ps, (float4*)q0, (float4*)q1,
                             (float4*)hits, slot_L, sample_slot, film_sum, film_sumsq, film_n, counters);
     return hipGetLastError();
 }

@@ -22,7 +22,7 @@ uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes, uin
 hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, bool shadow_only, const DScene& sc, const DCamera& cam, const DPass& ps,
                           const void* in_q, const void* in_counts, void* hits, uint32_t* cursor, float* slot_L, const uint32_t* film_n);
 hipError_t launch_fused_pass(hipStream_t stream, int num_cus, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t max_level_nodes, uint32_t records_per_sample,
-                             void* q0, void* q1, void* c0, void* c1, void* hits, float* slot_L, uint32_t* sample_slot,
+                             void* q0, void* q1, void* hits, float* slot_L, uint32_t* sample_slot,
                              float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters);
 // rows == null: the contiguous rows row_base .. row_base + nrows - 1
 hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t row_base, uint32_t nrows, uint32_t width, bool packed,

@@ -42,6 +42,7 @@ template <class T> bool Renderer::upload(T*& dptr, const void* src, size_t bytes
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
     allocs_.push_back(p);
+    alloc_bytes_ += bytes ? bytes : 16;
     if (bytes && src) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     else if (bytes) HIP_TRY(hipMemset(p, 0, bytes));
     dptr = static_cast<T*>(p);
@@ -121,7 +122,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
         nodes_per_sample = (uint32_t)first;
     }
     if (cfg.stripe_world <= 1) { cfg.stripe_world = 1; cfg.stripe_rank = 0; }
-    if (cfg.stripe_rows == 0) cfg.stripe_rows = 8;
+    if (cfg.stripe_rows == 0) cfg.stripe_rows = MI355RT_DEFAULT_STRIPE_ROWS;
     if (cfg.stripe_rank >= cfg.stripe_world) { err = "stripe_rank >= stripe_world"; return false; }
 
     code = MI355RT_E_NO_DEVICE;
@@ -419,7 +420,7 @@ void Renderer::free_pass_buffers()
         if (sl.d_slot_ps) { (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr; }
         if (sl.d_hits) { (void)hipFree(sl.d_hits); sl.d_hits = nullptr; }
         if (sl.d_hit_prim) { (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr; }
-        sl.capacity = 0;
+        sl.capacity = 0; sl.bytes = 0; sl.guards.clear();
     }
 }
 
@@ -433,7 +434,7 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
         (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr;
         (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr;
         (void)hipFree(sl.d_hits); sl.d_hits = nullptr; (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr;
-        sl.capacity = 0;
+        sl.capacity = 0; sl.bytes = 0; sl.guards.clear();
     }
     const size_t nchunks = (nsamples + chunk_ - 1) / chunk_;
     const size_t records = nchunks * chunk_ * records_per_sample_;
@@ -441,17 +442,30 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
     if (nsamples > 0x7FFFFFFFull || records > 0x0FFFFFFFull || nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 3ull > 0xFFFFFFFFull) {
         last_error = "pass too large"; alloc_failed_ = true; return false;     // the caller retries with a smaller pass
     }
+    // (n_radiance, n_shadow) per chunk: the fused 50-row launch cuts the same samples into chunks as small as kMinChunk
+    const size_t count_entries = nchunks * chunk_ / std::min(chunk_, kMinChunk);
+    // MI355RT_DEBUG_GUARD: every pass buffer gets a 256-byte tail filled with 0xA5 that check_guards() reads back
+    // (tests/test_gpu_dropin.py: no launch may write past the sizes computed here)
+    const size_t guard = getenv("MI355RT_DEBUG_GUARD") ? kGuardBytes : 0;
+    sl.guards.clear();
+    auto pass_alloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes + guard);
+        if (e == hipSuccess && guard) { e = hipMemset((char*)*p + bytes, 0xA5, guard); sl.guards.push_back((const uint8_t*)*p + bytes); }
+        return e;
+    };
     for (int i = 0; i < 2; ++i) {
-        HIP_ALLOC(hipMalloc(&sl.d_queue[i], records * kRayRecordBytes));
-        HIP_ALLOC(hipMalloc((void**)&sl.d_chunk_counts[i], nchunks * 8));
+        HIP_ALLOC(pass_alloc(&sl.d_queue[i], records * kRayRecordBytes));
+        HIP_ALLOC(pass_alloc((void**)&sl.d_chunk_counts[i], count_entries * 8));
     }
-    HIP_ALLOC(hipMalloc(&sl.d_hits, records * 16));
-    HIP_ALLOC(hipMalloc((void**)&sl.d_hit_prim, records * 4));
-    HIP_ALLOC(hipMalloc((void**)&sl.d_slot_L, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
-    HIP_ALLOC(hipMalloc((void**)&sl.d_sample_slot, nchunks * chunk_ * 4));
-    HIP_ALLOC(hipMalloc((void**)&sl.d_slot_ps, nchunks * chunk_ * 8));
+    HIP_ALLOC(pass_alloc(&sl.d_hits, records * 16));
+    HIP_ALLOC(pass_alloc((void**)&sl.d_hit_prim, records * 4));
+    HIP_ALLOC(pass_alloc((void**)&sl.d_slot_L, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
+    HIP_ALLOC(pass_alloc((void**)&sl.d_sample_slot, nchunks * chunk_ * 4));
+    HIP_ALLOC(pass_alloc((void**)&sl.d_slot_ps, nchunks * chunk_ * 8));
     sl.capacity = nsamples;
     sl.queue_records = records;
+    sl.count_entries = count_entries;
+    sl.bytes = 2 * (records * kRayRecordBytes + count_entries * 8) + records * 20 + nchunks * chunk_ * ((size_t)nodes_per_sample * std::max(nlights_, 1u) * 12 + 12);
     return true;
 }
 
@@ -727,14 +741,15 @@ uint32_t Renderer::trace_frame_additive()
         if (!ensure_pass_capacity(sl, nsamples)) return 0;
         DPass ps;
         uint32_t fchunk = 32u;                                            // samples per wave (a 4x8 pixel tile): 64 / 32 / 16 measure 0.303 / 0.266 / 0.277 ms per launch
-        if (const char* e = getenv("MI355RT_FUSED_CHUNK")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) fchunk = (uint32_t)v; }
+        if (const char* e = getenv("MI355RT_FUSED_CHUNK")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fchunk = (uint32_t)v; }   // <= 64: the LDS lists hold one row per record of a sample; >= kMinChunk: the counts arrays
         describe_pass(ps, sl, d_owned_rows_, (win.first + done) % nown, nown, (uint32_t)nsamples, nsamples, fchunk, false, 0, 0);
+        if (ps.nchunks > sl.count_entries || (size_t)ps.nchunks * ps.region > sl.queue_records) { last_error = "internal: fused pass does not fit the pass buffers"; return 0; }
         const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
         if (timed) {
             while (ev_used_ + 2 > ev_pool_.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { last_error = "hipEventCreate failed"; return 0; } ev_pool_.push_back(ev); }
             (void)hipEventRecord(ev_pool_[ev_used_], stream_);
         }
-        hipError_t e = launch_fused_pass(stream_, num_cus_, mode_ == kModeConfirm, dscene_, cam, ps, max_level_nodes_, records_per_sample_, sl.d_queue[0], sl.d_queue[1], sl.d_chunk_counts[0], sl.d_chunk_counts[1],
+        hipError_t e = launch_fused_pass(stream_, num_cus_, mode_ == kModeConfirm, dscene_, cam, ps, max_level_nodes_, records_per_sample_, sl.d_queue[0], sl.d_queue[1],
                                          sl.d_hits, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_counters_);
         if (e != hipSuccess) { fail(e, "fused pass launch"); return 0; }
         if (timed) { (void)hipEventRecord(ev_pool_[ev_used_ + 1], stream_); ev_used_ += 2; }
@@ -871,6 +886,30 @@ bool Renderer::synchronize()
     if (!bind()) return false;
     for (Slice& o : slices_) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
     return true;
+}
+
+// MI355RT_DEBUG_GUARD builds of the pass buffers: number of guard bytes that no longer hold the fill pattern (-1: error)
+long Renderer::check_guards()
+{
+    if (!bind()) return -1;
+    long bad = 0;
+    std::vector<uint8_t> h(kGuardBytes);
+    for (Slice& sl : slices_) {
+        if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess) return -1;
+        for (const uint8_t* g : sl.guards) {
+            if (hipMemcpy(h.data(), g, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            for (uint8_t b : h) bad += b != 0xA5;
+        }
+    }
+    return bad;
+}
+
+size_t Renderer::hbm_allocated_bytes() const
+{
+    size_t b = alloc_bytes_;
+    for (const Slice& sl : slices_) b += sl.bytes;
+    if (d_gather_) b += (size_t)slot_rows() * cfg.width * 4 * (gather_is_root_ ? cfg.stripe_world : 1);
+    return b;
 }
 
 // ---- multi-GPU gather ------------------------------------------------------------------------------------------

@@ -43,6 +43,9 @@ public:
     bool comm_init(const uint8_t* id128);                               // RCCL communicator over the stripe ranks (collective)
     bool comm_gather(uint32_t root, uint32_t* host_out, size_t n);      // collective: grouped ncclSend / ncclRecv to the root, then finish_gather there
     void comm_destroy();
+    uint32_t comm_ranks();                                              // ncclCommCount of the live communicator, 0 without one
+    long check_guards();                                                // MI355RT_DEBUG_GUARD: corrupted guard bytes behind the pass buffers
+    size_t hbm_allocated_bytes() const;                                 // device memory this handle holds (scene, film, pass buffers, gather slots)
     bool debug_slab(const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
     bool film_stat(bool variances, float* rgb);
     bool debug_numerics(const float* a, const float* b, size_t n, float* q, float* r, float* p);
@@ -94,6 +97,9 @@ private:
         uint32_t* d_sample_slot = nullptr;       // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
         size_t capacity = 0;                     // samples
         size_t queue_records = 0;
+        size_t count_entries = 0;                // entries of each d_chunk_counts array
+        size_t bytes = 0;                        // device memory of this slice's pass buffers
+        std::vector<const uint8_t*> guards;      // MI355RT_DEBUG_GUARD: the 0xA5-filled tails of the pass buffers
     };
     bool ensure_pass_capacity(Slice& sl, size_t nsamples);
     void free_pass_buffers();
@@ -121,6 +127,7 @@ private:
     std::vector<hipEvent_t> ev_pool_;
     size_t ev_used_ = 0;
     std::vector<void*> allocs_;
+    size_t alloc_bytes_ = 0;             // bytes behind allocs_ (scene, acceleration structures, film, row lists, cursors)
 
     DScene dscene_{};
     float* d_film_sum_ = nullptr; float* d_film_sumsq_ = nullptr; uint32_t* d_film_n_ = nullptr;
@@ -141,6 +148,8 @@ private:
     uint32_t rows_assigned_for_ = 0;     // number of slices the row lists were last split into
     uint32_t active_slices_ = 1;         // slices used by the call in flight (begin_call .. end_call)
     uint32_t chunk_ = 256;               // primary samples per work chunk
+    static constexpr size_t kGuardBytes = 256;
+    static constexpr uint32_t kMinChunk = 16;   // smallest chunk any launcher cuts a pass into (the fused 50-row launch: 16 / 32 / 64)
     uint32_t max_level_nodes_ = 1;
     uint32_t leaf_threshold_ = 16;
     bool alloc_failed_ = false;          // the last ensure_pass_capacity failure was an out-of-memory

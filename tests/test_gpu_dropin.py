@@ -276,3 +276,37 @@ def test_set_seed_and_set_flags_semantics(pkg, scenes, oracle):
     oo = oracle.Oracle(scenes("4boxes"), w, h, seed=2, flags=oracle.FLAG_FIX_ROW_INDEX)
     o.render(2); oo.render(2, nthreads=4)
     assert np.array_equal(bits(o.film.pixel_datas()[0]), bits(oo.film()[0]))   # still the reference-exact octree, 4boxes shows it
+
+
+def test_no_launch_writes_past_a_pass_buffer(pkg, scenes, monkeypatch):
+    """Guard regions (MI355RT_DEBUG_GUARD: 256 bytes of 0xA5 behind every pass buffer).  A FRESH handle whose first call is
+    trace_frame_additive sizes its buffers for 50 rows and then cuts them into chunks of 16 / 32 / 64 samples for the fused
+    launch (the per-chunk count arrays were once sized for 256-sample chunks only); then whole frames on the same handle
+    (buffers grow), then 50-row frames again through the wavefront rounds.  No guard byte may change, and the films of the
+    chunk sizes are identical."""
+    monkeypatch.setenv("MI355RT_DEBUG_GUARD", "1")
+    films = []
+    for fchunk in ("16", "32", "64"):
+        monkeypatch.setenv("MI355RT_FUSED_CHUNK", fchunk)
+        rt = make(pkg, scenes, "thai2", 1024, 768, seed=4)
+        for _ in range(3):
+            assert rt.trace_frame_additive() == 50 * 1024
+        rt.last_counts()
+        assert rt.debug_check_guards() == 0, fchunk
+        films.append(rt.film.pixel_datas())
+        rt.render(2)
+        assert rt.debug_check_guards() == 0, fchunk
+        monkeypatch.setenv("MI355RT_NO_FUSED", "1")
+        rt.trace_frame_additive(); rt.last_counts()
+        monkeypatch.delenv("MI355RT_NO_FUSED")
+        assert rt.debug_check_guards() == 0, fchunk
+        assert rt.hbm_allocated_bytes() > 0
+        del rt
+    for s, q, n in films[1:]:
+        assert np.array_equal(n, films[0][2]) and np.array_equal(bits(s), bits(films[0][0])) and np.array_equal(bits(q), bits(films[0][1]))
+    # multi-slice frame: every slice's buffers are guarded
+    monkeypatch.delenv("MI355RT_FUSED_CHUNK")
+    rt = make(pkg, scenes, "ico2", 640, 360, seed=4)
+    rt.set_slices(3)
+    rt.render(4)
+    assert rt.debug_check_guards() == 0
