@@ -7,28 +7,42 @@ mapping, seed 1, followed by the tonemapped read-out into device memory and (N >
 stripes.  Scene, BVH and film are resident in HBM before the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 started WITHOUT a launcher (no WORLD_SIZE in the environment) launches itself: the parent — before it imports
+torch or touches the GPU — starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free> bench.py <same arguments>` as a child process and exits with its code.  Started under a launcher
+(WORLD_SIZE set) it is one of the ranks.
 
   --scaling weak (default)  every GPU traces 1920*1080*64 primary samples; with N GPUs the frame is the same image
-                            at 64*N spp, rows dealt to the ranks in stripes of 8.
+                            at 64*N spp, rows dealt to the ranks in stripes.
   --scaling strong          the frame is FIXED (1920x1080x64 spp, or --config c5: 3840x2160x256 spp, BASELINE config 5)
                             and its rows are dealt to the N ranks.
   --mode dropin             the loop the reference binary runs (main.rs:197-207) at its defaults (thai2, 1024x768):
                             a step is trace_frame_additive() + get_tonemapped_pixels(); metric = primary rays/s,
                             the reference's own stats.rs:27 definition.  N = 1 only.
 
-Rank 0 prints ONE JSON line (see the repo instructions for the contract).  Extra objects:
-  roofline      dominant kernel = trace_kernel (closest-hit traversal).  It is bound by vector-ALU ISSUE, not by
-                memory (the 1.5 MB scene is cache-resident): `bound` = "valu", achieved = VALU wave-instructions per
-                second of the secondary trace launches (SQ_INSTS_VALU of a rocprofv3 --pmc child pass of THIS run /
-                HIP-event launch time), peak = 1024 SIMDs x clock / 4 cycles per wave64 instruction.  Next to it:
-                the useful-lane fractions of the inner-node and triangle sections (live, MI355RT_FLAG_COUNT_STEPS),
-                the SURVEY.md 8d LOGICAL byte rate (labelled logical: it exceeds the HBM peak because node and
-                triangle bytes are cache hits) and the measured HBM traffic per launch (`traffic`, PMC FETCH_SIZE x 2 +
-                WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  PMC fields are null when the child passes
-                are skipped (--no-pmc, N > 1) or fail.
+Rank 0 prints ONE JSON line (see the repo instructions for the contract).  The default run (weak, c4) carries three result
+groups: the line itself (weak scaling: what the driver's scaling curve is made of), `strong` (the fixed 1080p x 64 frame
+dealt to the N ranks) and `c5` (BASELINE config 5, the fixed 3840x2160 x 256 frame dealt to the N ranks), each with its own
+ms_per_step, gather_ms_rank0, gather_path ("none" | "library_rccl" | "torch_all_gather"), rccl_ranks (what ncclCommCount
+returned) and gather_error (null unless the library's RCCL path was refused and torch's all_gather stood in).
+Extra objects of the line:
+  roofline      dominant kernel = trace_kernel (closest-hit traversal), secondary launches.  It is bound by vector-ALU
+                ISSUE, not by memory (the 1.5 MB scene is cache-resident): `bound` = "valu";
+                achieved = SQ_INSTS_VALU per secondary trace launch (a rocprofv3 --pmc child pass of THIS run)
+                           / the average duration of a secondary trace launch (HIP events around those launches, this process);
+                peak     = 1024 SIMDs x 2400 MHz / 4 cycles per wave64 VALU instruction; frac = achieved / peak.
+                Next to it: the clock the trace waves were observed to run at (s_memtime / s_memrealtime inside the
+                instrumented launch) and frac against THAT clock, the SQ busy-cycle issue fraction (a separate field), the
+                useful-lane fractions of the inner-node and triangle sections (live, MI355RT_FLAG_COUNT_STEPS), the SURVEY.md 8d
+                LOGICAL byte rate (labelled logical: it exceeds the HBM peak because node and triangle bytes are cache
+                hits) and the measured HBM traffic per launch (`traffic`, PMC FETCH_SIZE x 2 + WRITE_SIZE as
+                MI355X_MICROARCH.md prescribes for gfx950).  PMC fields are null when the child passes are skipped
+                (--no-pmc, N > 1) or fail.
   cpu_baseline  the CPU oracle (C restatement of the reference: octree, recursive radiance) timed on this box's
                 host cores on a bounded sample of the same workload.
+  dropin        (N = 1) the loop the reference binary runs, trace_frame_additive() + get_tonemapped_pixels() at 1024x768:
+                ms per step, primary rays/s, and the CPU oracle's same loop beside it.
 """
 import argparse
 import csv
@@ -36,6 +50,7 @@ import glob
 import json
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -50,9 +65,10 @@ STRIPE_ROWS = 2                 # rows per stripe of the deal over ranks and sli
 HBM_PEAK_GBS = 8000.0
 NUM_SIMDS = 1024            # 256 CUs x 4
 NUM_SE = 32                 # 8 XCDs x 4 shader engines: SQ_BUSY_CYCLES is summed over them
+NOMINAL_MHZ = 2400.0        # MI355X_MICROARCH.md: max clock
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
@@ -64,6 +80,8 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline PMC fields become null)")
+    ap.add_argument("--no-groups", action="store_true", help="default run only: skip the `strong` and `c5` result groups")
+    ap.add_argument("--no-dropin", action="store_true", help="default N = 1 run only: skip the `dropin` object")
     ap.add_argument("--native-gather", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: gather the stripes with the library's own RCCL path (on), torch.distributed (off), or try native first")
     ap.add_argument("--stripe-rows", type=int, default=0, help="rows per stripe of the deal over ranks (and of the blocks dealt to the frame slices); 0: the default")
@@ -73,8 +91,9 @@ def parse_args():
     ap.add_argument("--fix-row-index", action="store_true",
                     help="v = idx / width instead of the reference's idx / height (SURVEY.md 8d: reported next to the headline, never as it)")
     ap.add_argument("--slices", type=int, default=0, help="concurrent frame slices of the timed frames (0: library default)")
+    ap.add_argument("--spawn", action="store_true", help="launch the rank processes from here even for N = 1 (what N > 1 without a launcher does)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.stripe_rows > 0:
         global STRIPE_ROWS
         STRIPE_ROWS = args.stripe_rows
@@ -86,10 +105,34 @@ def parse_args():
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks from here.  The parent has imported neither torch nor the library and has made
+# no HIP call; the ranks are fresh child processes (never an exec of a process that has touched the GPU).
+def spawn_command(args, argv):
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    child_args = [a for a in argv if a != "--spawn"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + child_args
+
+
+def self_launch(args, argv):
+    cmd = spawn_command(args, argv)
+    if os.environ.get("MI355RT_BENCH_DRY_SPAWN") == "1":           # tests: what would be started, and what the parent has loaded
+        print(json.dumps({"spawn": cmd, "torch_imported": "torch" in sys.modules, "library_imported": "raytracer_rs_amd" in sys.modules}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: what RCCL needs between processes on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # rocprofv3 --pmc child passes (N = 1, rank 0, BEFORE this process touches the GPU): the same frame under counter
 # collection, one pass per counter group (TCC slots: FETCH_SIZE and WRITE_SIZE cannot share a pass).
 PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"],
               ["FETCH_SIZE"], ["WRITE_SIZE"]]
+PMC_CHILD_FRAMES = 2
 
 
 def pmc_child(args):
@@ -105,10 +148,10 @@ def pmc_child(args):
             rt.trace_frame_additive()
         rt.get_tonemapped_pixels()
         return
-    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, WIDTH, HEIGHT, seed=1,
+    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, WIDTH, HEIGHT, seed=1, stripe_rows=STRIPE_ROWS,
                                           flags=(pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0) | (pkg.FLAG_TRUE_CLOSEST_HIT if args.true_closest_hit else 0))
     rt.set_slices(1)
-    for _ in range(2):
+    for _ in range(PMC_CHILD_FRAMES):
         rt.film.clear()
         rt.render(args.spp or SPP)
 
@@ -122,7 +165,8 @@ def run_pmc_passes(args, kernel_substr):
     base = tempfile.mkdtemp(prefix="mi355rt_pmc_", dir="/tmp")
     env = dict(os.environ); env["TMPDIR"] = "/tmp"
     child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
-             "--mode", args.mode, "--scene", args.scene] + (["--fix-row-index"] if args.fix_row_index else []) + (["--true-closest-hit"] if args.true_closest_hit else []) + (["--spp", str(args.spp)] if args.spp else [])
+             "--mode", args.mode, "--scene", args.scene] + (["--fix-row-index"] if args.fix_row_index else []) + (["--true-closest-hit"] if args.true_closest_hit else []) \
+        + (["--spp", str(args.spp)] if args.spp else []) + (["--stripe-rows", str(args.stripe_rows)] if args.stripe_rows else [])
     note = None
     try:
         for gi, group in enumerate(PMC_GROUPS):
@@ -137,7 +181,6 @@ def run_pmc_passes(args, kernel_substr):
                 note = "rocprofv3 pass %d failed (rc %d): %s" % (gi, r.returncode, (r.stderr or "")[-200:].replace("\n", " "))
                 break
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-                seen = {}
                 for row in csv.DictReader(open(f)):
                     if kernel_substr not in row["Kernel_Name"]:
                         continue
@@ -185,39 +228,178 @@ def oracle_build_flags(ge):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def main():
-    args = parse_args()
+class Ctx:
+    """what every result group needs: the package, the scene, the process group"""
+
+
+class FrameSetup:
+    """One handle of a result group + its gather transport.
+
+    gather_path   "none" (1 GPU) | "library_rccl" (mi355rt_comm_*: grouped ncclSend / ncclRecv to rank 0 inside the library,
+                  checked against torch's all_gather on one frame before anything is timed) | "torch_all_gather"
+    gather_error  null, or why the library's RCCL path was not used although it was asked for (never hidden in a string elsewhere)
+    rccl_ranks    ncclCommCount of the library's communicator (0 without one)"""
+
+    def __init__(self, ctx, width, height, spp, flags):
+        import torch
+        pkg, args = ctx.pkg, ctx.args
+        self.ctx, self.width, self.height, self.spp = ctx, width, height, spp
+        self.rt = pkg.create_raytracer_from_arrays(ctx.scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, width, height, seed=1, device=ctx.local_rank,
+                                                   stripe_rows=STRIPE_ROWS, stripe_rank=ctx.rank, stripe_world=ctx.world, flags=flags)
+        self.base_flags = (pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0) | flags
+        self.rt.set_flags(self.base_flags)
+        if args.slices:
+            self.rt.set_slices(args.slices)
+        self.slices = self.rt.get_slices()
+        self.rows = self.rt.owned_rows()
+        assert list(self.rows) == ctx.stripes.owned_rows(height, STRIPE_ROWS, ctx.rank, ctx.world)
+        self.fg = ctx.stripes.FrameGather(height, width, STRIPE_ROWS, ctx.world, "cuda")
+        self.stripe = self.fg.stripe_buffer("cuda")
+        self.cur_stream = torch.cuda.current_stream().cuda_stream
+        self.native = None
+        self.gather_path, self.gather_error, self.rccl_ranks = ("none" if ctx.world == 1 else "torch_all_gather"), None, 0
+        if ctx.world > 1 and args.native_gather != "off":
+            try:
+                self.native = ctx.stripes.NativeGather(pkg, self.rt, ctx.dist, ctx.rank, ctx.world)
+                self.rt.film.clear(); self.rt.render(1)                # one cheap frame through both transports before anything is timed
+                if not self.native.verify_against(ctx.dist, ctx.rank, self.fg, self.stripe):
+                    self.native.close(); self.native = None
+                    raise RuntimeError("the library's RCCL gather did not reproduce the all_gather frame")
+                self.gather_path, self.rccl_ranks = "library_rccl", self.native.ranks
+            except Exception as e:                                     # noqa: BLE001 — every rank takes this branch together (NativeGather agrees on failures)
+                if args.native_gather == "on":
+                    raise
+                self.native = None
+                self.gather_error = str(e)[:300]
+        self.gather_ms = []
+
+    def sync(self):
+        import torch
+        self.rt.synchronize()                                           # the library's own streams (frames, the native gather)
+        if self.ctx.dist is not None:
+            self.ctx.dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(self, time_gather=False):
+        import torch
+        rt = self.rt
+        rt.film.clear()
+        counts = rt.render(self.spp)                                    # synchronous: returns when the frame is traced
+        t0 = time.perf_counter()
+        if self.native is not None:
+            self.native.gather()                                        # tonemap + RCCL inside the library, on its own stream
+        else:
+            rt.tonemap_owned_rows_device(self.stripe.data_ptr(), self.rows.size * self.width, stream=self.cur_stream)   # ordered on torch's stream
+            self.fg.gather(self.ctx.dist, self.stripe)
+        if time_gather:
+            rt.synchronize(); torch.cuda.synchronize()
+            self.gather_ms.append((time.perf_counter() - t0) * 1e3)
+        return counts
+
+    def timed(self, steps, warmup):
+        """`warmup` untimed frames, then EXACTLY `steps` frames between two (barrier + device synchronisation)s;
+        -> elapsed seconds (max over ranks), ray sums over ranks, rank-0 per-step times"""
+        import torch
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        tot = [0.0, 0.0, 0.0, 0.0]
+        step_ms = []
+        for _ in range(steps):
+            ts = time.perf_counter()
+            c = self.step()                                             # the frame is complete when render() returns; the gather is queued
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+            tot[0] += c.primary; tot[1] += c.bounce; tot[2] += c.shadow; tot[3] += c.primary_culled
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        for _ in range(2):                                              # the gather timed on its own (render excluded)
+            self.step(time_gather=True)
+        self.sync()
+        stats = torch.tensor([elapsed] + tot, dtype=torch.float64, device="cuda")
+        dist = self.ctx.dist
+        if dist is not None:
+            tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            sums = stats[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            elapsed = float(tmax[0]); vals = [float(x) for x in sums]
+        else:
+            vals = [float(x) for x in stats[1:]]
+        return elapsed, vals, step_ms
+
+    def summary(self, workload, scaling, steps, warmup, elapsed, vals):
+        primary, bounce, shadow, culled = vals
+        total = primary + bounce + shadow
+        return {"workload": workload, "scaling": scaling, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(elapsed / steps * 1e3, 3), "value": round(total / elapsed / 1e6, 2), "unit": "Mrays/s",
+                "traced_mrays_per_s": round((total - culled) / elapsed / 1e6, 2),
+                "gather_ms_rank0": round(sorted(self.gather_ms)[len(self.gather_ms) // 2], 3) if self.gather_ms else None,
+                "gather_path": self.gather_path, "rccl_ranks": self.rccl_ranks, "gather_error": self.gather_error,
+                "slices": self.slices, "hbm_allocated_bytes_rank0": self.rt.hbm_allocated_bytes()}
+
+    def close(self):
+        if self.native is not None:
+            self.native.close(); self.native = None
+        self.rt = None
+
+
+def workload_text(args, width, height, spp, base_spp, world, scaling, c5=False):
+    if scaling == "strong":
+        w = "%s %dx%d x %d spp FIXED frame dealt to %d GPU(s) in row stripes of %d (strong scaling%s)" % (
+            args.scene, width, height, spp, world, STRIPE_ROWS, ", BASELINE config 5" if c5 else "")
+    else:
+        w = "%s %dx%d, %d spp per GPU (frame = %d spp), rows dealt in stripes of %d" % (args.scene, width, height, base_spp, spp, STRIPE_ROWS)
+    w += ", recursions 2 / spread 1, " + ("row index FIXED (v = idx / width)" if args.fix_row_index else "reference pixel mapping")
+    w += ", intersector semantics: " + ("true closest hit (NoAccelerationIntersector, opt-out flag)" if args.true_closest_hit else
+                                        "the reference's default OctTreeIntersector at 70 triangles per leaf (BVH + octree confirm step)")
+    return w
+
+
+def extra_group(ctx, name, sem_flag):
+    """the `strong` / `c5` result groups of the default run: the fixed frame dealt to the ranks, a few frames"""
+    args = ctx.args
+    width, height, spp = (3840, 2160, 256) if name == "c5" else (WIDTH, HEIGHT, SPP)
+    steps, warmup = (3, 1) if name == "c5" else (min(args.steps, 5), 1)
+    fs = FrameSetup(ctx, width, height, spp, sem_flag)
+    elapsed, vals, _ = fs.timed(steps, warmup)
+    out = fs.summary(workload_text(args, width, height, spp, spp, ctx.world, "strong", c5=name == "c5"), "strong", steps, warmup, elapsed, vals)
+    fs.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
     if args.pmc_child:
         return pmc_child(args)
+    if args.mode == "dropin" and args.gpus != 1:
+        raise SystemExit("--mode dropin is a single-GPU loop")
+    if args.config == "c5" and args.scaling != "strong":
+        raise SystemExit("--config c5 is the fixed 3840x2160x256 frame: use --scaling strong")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(self_launch(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
-    if args.mode == "dropin" and world != 1:
-        raise SystemExit("--mode dropin is a single-GPU loop")
-    if args.config == "c5" and args.scaling != "strong":
-        raise SystemExit("--config c5 is the fixed 3840x2160x256 frame: use --scaling strong")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     # counter passes first: this process has not initialised the GPU yet, so the children have the device to themselves
     pmc, pmc_note = ({}, "skipped (--no-pmc)") if args.no_pmc else ({}, "skipped (N > 1)")
     if not args.no_pmc and world == 1:
         pmc, pmc_note = run_pmc_passes(args, "fused_pass_kernel" if args.mode == "dropin" else "trace_kernel<false, false")
 
-    import numpy as np
-    import torch
+    import torch                                                       # before the library: see raytracer-rs_amd/__init__.py lib()
     import __graft_entry__ as ge
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    if os.environ.get("MI355RT_BENCH_SHARE_GPU") != "1":
-        torch.cuda.set_device(local_rank)
-    dist = None
     share_gpu = os.environ.get("MI355RT_BENCH_SHARE_GPU") == "1"       # rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, gloo
     if share_gpu:
         local_rank = 0
-        torch.cuda.set_device(0)
+    torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -231,66 +413,23 @@ def main():
     scene_io = importlib.import_module("raytracer_rs_amd.scene_io")
     scene = scene_io.load_scene_file(os.path.join(ge.SCENES, args.scene + ".scene"))
     if args.mode == "dropin":
-        return dropin_mode(args, ge, pkg, scene, pmc, pmc_note)
+        out = dropin_measure(args, ge, pkg, scene, pmc, pmc_note, full=True)
+        print(json.dumps(out), flush=True)
+        return
+
+    ctx = Ctx()
+    ctx.args, ctx.pkg, ctx.scene, ctx.dist, ctx.rank, ctx.world, ctx.local_rank = args, pkg, scene, dist, rank, world, local_rank
+    ctx.stripes = importlib.import_module("raytracer_rs_amd.stripes")
 
     width, height = (3840, 2160) if args.config == "c5" else (WIDTH, HEIGHT)
     base_spp = args.spp or (256 if args.config == "c5" else SPP)
     spp = base_spp * world if args.scaling == "weak" else base_spp
     sem_flag = (pkg.FLAG_TRUE_CLOSEST_HIT if args.true_closest_hit else 0) | (pkg.FLAG_DEVICE_LBVH if args.device_lbvh else 0)
-    rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, width, height, seed=1, device=local_rank,
-                                          stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_world=world, flags=sem_flag)
-    base_flags = (pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0) | sem_flag
-    rt.set_flags(base_flags)
-    if args.slices:
-        rt.set_slices(args.slices)
-    slices = rt.get_slices()
-    stripes = importlib.import_module("raytracer_rs_amd.stripes")
-    rows = rt.owned_rows()
-    assert list(rows) == stripes.owned_rows(height, STRIPE_ROWS, rank, world)
-    fg = stripes.FrameGather(height, width, STRIPE_ROWS, world, "cuda")
-    stripe = fg.stripe_buffer("cuda")
-    gather_kind = "none (1 GPU)"
-    native = None
-    if world > 1 and args.native_gather != "off":
-        try:
-            native = stripes.NativeGather(pkg, rt, dist, rank, world)
-            rt.film.clear(); rt.render(1)                             # one cheap frame through both transports before anything is timed
-            if not native.verify_against(dist, rank, fg, stripe):
-                native.close(); native = None
-                raise RuntimeError("the library's RCCL gather did not reproduce the all_gather frame")
-            gather_kind = "library RCCL (mi355rt_comm_*: grouped ncclSend/ncclRecv of the u32 stripes to rank 0 + broadcast-free placement; checked against all_gather on one frame)"
-        except Exception as e:                                    # noqa: BLE001 — fall back to torch.distributed, say so in the line
-            if args.native_gather == "on":
-                raise
-            native = None
-            gather_kind = "torch.distributed all_gather_into_tensor (library RCCL path unavailable: %s)" % str(e)[:120]
-    elif world > 1:
-        gather_kind = "torch.distributed all_gather_into_tensor"
-    cur_stream = torch.cuda.current_stream().cuda_stream
+    fs = FrameSetup(ctx, width, height, spp, sem_flag)
+    rt, base_flags = fs.rt, fs.base_flags
 
-    def sync():
-        rt.synchronize()                                           # the library's own streams (frames, the native gather)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    gather_ms = []
-
-    def step(time_gather=False):
-        rt.film.clear()
-        counts = rt.render(spp)                                   # synchronous: returns when the frame is traced
-        t0 = time.perf_counter()
-        if native is not None:
-            native.gather()                                        # tonemap + RCCL inside the library, on its own stream
-        else:
-            rt.tonemap_owned_rows_device(stripe.data_ptr(), rows.size * width, stream=cur_stream)   # ordered on torch's stream
-            fg.gather(dist, stripe)
-        if time_gather:
-            rt.synchronize(); torch.cuda.synchronize()
-            gather_ms.append((time.perf_counter() - t0) * 1e3)
-        return counts
-
-    # instrumented frame (untimed): nodes visited / triangles tested per ray, useful-lane fractions of the two sections
+    # instrumented frame (untimed): nodes visited / triangles tested per ray, useful-lane fractions of the two sections,
+    # and the clock the trace waves run at (s_memtime against s_memrealtime, stamped by the instrumented build only)
     rt.set_flags(base_flags | pkg.FLAG_COUNT_STEPS)
     rt.film.clear()
     c = rt.render(max(1, min(4, spp)))
@@ -299,50 +438,42 @@ def main():
     tris_per_ray = c.tris_tested / inst_rays
     lane_inner = c.nodes_visited / (64.0 * c.inner_execs) if c.inner_execs else None
     lane_leaf = c.tris_tested / (64.0 * c.leaf_execs) if c.leaf_execs else None
+    observed_mhz = c.shader_clock_mhz or None
     rt.set_flags(base_flags)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    tot = dict(primary=0, bounce=0, shadow=0, culled=0, trace_ms=0.0, launches=0, gpu_ms=0.0)
-    step_ms = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        c = step()                                                 # the frame is complete when render() returns; the gather is queued
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-        tot["primary"] += c.primary; tot["bounce"] += c.bounce; tot["shadow"] += c.shadow; tot["culled"] += c.primary_culled
-    sync()
-    elapsed = time.perf_counter() - t0
-
-    # gather timed on its own (render excluded): a few frames with a device synchronisation after the gather
-    for _ in range(2):
-        step(time_gather=True)
-    sync()
+    elapsed, vals, step_ms = fs.timed(args.steps, args.warmup)
+    primary, bounce, shadow, culled = vals
+    total_rays = primary + bounce + shadow
 
     # Kernel-timing loop for the roofline: the same frames again with ONE slice and HIP events around every
     # trace launch (on the stream it is launched on).  The frames above run several slices concurrently:
     # their kernels share the chip and have no individual duration, so the per-launch time is taken here.
     rt.set_slices(1)
     rt.set_flags(base_flags | pkg.FLAG_TIME_KERNELS)
-    step()
+    fs.step()
     ksteps = max(1, min(args.steps, 3))
-    sync()
+    fs.sync()
     t1 = time.perf_counter()
-    krays = 0
+    k = dict(rays=0, sec_rays=0, trace_ms=0.0, sec_ms=0.0, launches=0, sec_launches=0)
     for _ in range(ksteps):
-        c = step()
-        krays += c.primary + c.bounce + c.shadow
-        tot["trace_ms"] += c.trace_ms; tot["launches"] += c.trace_launches; tot["gpu_ms"] += c.total_ms
-    sync()
+        c = fs.step()
+        k["rays"] += c.primary + c.bounce + c.shadow; k["sec_rays"] += c.bounce + c.shadow
+        k["trace_ms"] += c.trace_ms; k["sec_ms"] += c.trace_secondary_ms
+        k["launches"] += c.trace_launches; k["sec_launches"] += c.trace_secondary_launches
+    fs.sync()
     serial_ms_per_step = (time.perf_counter() - t1) / ksteps * 1e3
+    rt.set_flags(base_flags)
+    main_group = fs.summary(workload_text(args, width, height, spp, base_spp, world, args.scaling, c5=args.config == "c5"), args.scaling, args.steps, args.warmup, elapsed, vals)
+    acc = rt.accel_stats()
+    build_info = rt.bvh_build_info()
+    slices = fs.slices
+    fs.close(); del rt
 
     # the other intersector semantics on the same frame (short: 1 warm + 3 timed frames), for the record in the line
     other = None
     if world == 1:
-        del rt
         oflag = (0 if args.true_closest_hit else pkg.FLAG_TRUE_CLOSEST_HIT) | (pkg.FLAG_DEVICE_LBVH if args.device_lbvh else 0)
-        rt2 = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, width, height, seed=1, device=local_rank, flags=oflag)
+        rt2 = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, width, height, seed=1, device=local_rank, stripe_rows=STRIPE_ROWS, flags=oflag)
         rt2.set_flags(oflag | (pkg.FLAG_FIX_ROW_INDEX if args.fix_row_index else 0))
         if args.slices:
             rt2.set_slices(args.slices)
@@ -353,123 +484,119 @@ def main():
         dt2 = time.perf_counter() - t2
         other = {"semantics": "reference default (octree)" if args.true_closest_hit else "true closest hit (MI355RT_FLAG_TRUE_CLOSEST_HIT)",
                  "ms_per_step": round(dt2 / 3 * 1e3, 3), "mrays_per_s": round(r2 / dt2 / 1e6, 2)}
-        rt = rt2
+        del rt2
 
-    stats = torch.tensor([elapsed, tot["primary"], tot["bounce"], tot["shadow"], tot["culled"], tot["trace_ms"], tot["launches"], krays],
-                         dtype=torch.float64, device="cuda")
-    if dist is not None:
-        tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        sums = stats[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0]); vals = [float(x) for x in sums]
-    else:
-        vals = [float(x) for x in stats[1:]]
-    primary, bounce, shadow, culled, trace_ms, launches, krays = vals
-    total_rays = primary + bounce + shadow
+    # the other two result groups of the default run (collective: every rank takes part)
+    groups = {}
+    if args.scaling == "weak" and args.config == "c4" and not args.no_groups and not args.spp:
+        for name in ("strong", "c5"):
+            groups[name] = extra_group(ctx, name, sem_flag)
 
     if rank == 0:
-        acc = rt.accel_stats()
         node_bytes = acc["node_bytes"] / max(acc["nodes"], 1)
         bytes_per_ray = node_bytes * nodes_per_ray + 48.0 * tris_per_ray + 96.0
-        avg_launch_s = trace_ms * 1e-3 / max(launches, 1)
-        logical_gbs = krays * bytes_per_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-        prop = torch.cuda.get_device_properties(local_rank)
-        clock_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
-        peak_winst = NUM_SIMDS * clock_hz / 4.0 / 1e9                     # G wave64 VALU instructions per second
+        prim_launches = k["launches"] - k["sec_launches"]
+        sec_launch_s = k["sec_ms"] * 1e-3 / max(k["sec_launches"], 1)
+        prim_launch_s = (k["trace_ms"] - k["sec_ms"]) * 1e-3 / max(prim_launches, 1)
+        logical_gbs = k["rays"] * bytes_per_ray / (k["trace_ms"] * 1e-3) / 1e9 if k["trace_ms"] > 0 else 0.0
+        peak_winst = NUM_SIMDS * NOMINAL_MHZ * 1e6 / 4.0 / 1e9                     # G wave64 VALU instructions per second
         roof = {"bound": "valu", "kernel": "trace_kernel<secondary>", "unit": "G wave-instr/s", "peak": round(peak_winst, 1),
-                "peak_is": "%d SIMDs x %.0f MHz / 4 cycles per wave64 VALU instruction" % (NUM_SIMDS, clock_hz / 1e6),
+                "peak_is": "%d SIMDs x %.0f MHz (nominal maximum clock) / 4 cycles per wave64 VALU instruction" % (NUM_SIMDS, NOMINAL_MHZ),
                 "achieved": None, "frac": None,
+                "achieved_is": "SQ_INSTS_VALU per secondary trace launch (rocprofv3 --pmc child of this run) / average duration of a secondary trace launch (HIP events, this process)",
+                "clock_mhz_nominal": NOMINAL_MHZ, "clock_mhz_observed": round(observed_mhz, 1) if observed_mhz else None,
+                "clock_observed_is": "sum of delta s_memtime / sum of delta s_memrealtime x 100 MHz over all waves of the instrumented frame's trace launches",
+                "frac_of_observed_clock_peak": None,
                 "useful_lane_frac_inner": round(lane_inner, 3) if lane_inner else None, "useful_lane_frac_leaf": round(lane_leaf, 3) if lane_leaf else None,
-                "launches": int(launches), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                "secondary_launches": int(k["sec_launches"]), "avg_secondary_launch_ms": round(sec_launch_s * 1e3, 4),
+                "primary_launches": int(prim_launches), "avg_primary_launch_ms": round(prim_launch_s * 1e3, 4),
+                "secondary_rays_per_launch": round(k["sec_rays"] / max(k["sec_launches"], 1), 1),
                 "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2), "node_bytes": node_bytes,
                 "logical": {"what": "SURVEY.md 8d algorithmic bytes: node_bytes x nodes + 48 x triangles + 96 per ray; node and triangle bytes are CACHE hits "
                                     "(1.5 MB scene), so this is not HBM traffic and may exceed the HBM peak",
-                            "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_launch": round(krays * bytes_per_ray / max(launches, 1), 1),
+                            "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_launch": round(k["rays"] * bytes_per_ray / max(k["launches"], 1), 1),
                             "gbs": round(logical_gbs, 1), "frac_of_hbm_peak": round(logical_gbs / HBM_PEAK_GBS, 4)},
                 "traffic": None, "hbm": None,
                 "timing": "HIP events around every trace launch in a second loop of %d frames with 1 slice (%.2f ms/frame); the headline frames run %d "
                           "concurrent slices whose kernels overlap" % (ksteps, serial_ms_per_step, slices),
-                "pmc": {"source": "rocprofv3 --pmc child passes of this same run (bench.py --pmc-child: 2 frames, 1 slice), secondary trace launches", "note": pmc_note}}
-        # per secondary trace launch of the child == per secondary trace launch here (same frame, same binary)
-        rays_per_sec_launch = (bounce + shadow) / max(args.steps * world, 1)     # secondary rays per frame per GPU ...
+                "pmc": {"source": "rocprofv3 --pmc child passes of this same run (bench.py --pmc-child: %d frames, 1 slice), secondary trace launches" % PMC_CHILD_FRAMES, "note": pmc_note}}
         if "SQ_INSTS_VALU" in pmc:
             v, n = pmc["SQ_INSTS_VALU"]
-            frame_launches = n / 2.0                                             # the child renders 2 frames
-            inst_per_frame = v / 2.0
-            sec_rays_frame = rays_per_sec_launch
-            sec_ms_frame = None
-            # secondary launches' share of the HIP-event trace time: the child has no timing, use the avg launch duration of this run's loop
+            inst_per_launch = v / max(n, 1)
+            sec_rays_launch = k["sec_rays"] / max(k["sec_launches"], 1)
             roof["pmc"]["dispatches"] = n
-            roof["pmc"]["valu_winst_per_secondary_ray"] = round(inst_per_frame / max(sec_rays_frame, 1), 2)
-            roof["pmc"]["salu_inst_per_secondary_ray"] = round(pmc.get("SQ_INSTS_SALU", (0, 0))[0] / 2.0 / max(sec_rays_frame, 1), 2)
+            roof["pmc"]["valu_winst_per_launch"] = round(inst_per_launch, 1)
+            roof["pmc"]["valu_winst_per_secondary_ray"] = round(inst_per_launch / max(sec_rays_launch, 1), 2)
+            roof["pmc"]["salu_inst_per_secondary_ray"] = round(pmc.get("SQ_INSTS_SALU", (0, 0))[0] / max(n, 1) / max(sec_rays_launch, 1), 2)
+            if sec_launch_s > 0:
+                achieved = inst_per_launch / sec_launch_s / 1e9
+                roof["achieved"] = round(achieved, 1)
+                roof["frac"] = round(achieved / peak_winst, 4)
+                if observed_mhz:
+                    roof["frac_of_observed_clock_peak"] = round(achieved / (NUM_SIMDS * observed_mhz * 1e6 / 4.0 / 1e9), 4)
             if "SQ_BUSY_CYCLES" in pmc and pmc["SQ_BUSY_CYCLES"][0] > 0:
                 busy = pmc["SQ_BUSY_CYCLES"][0] / NUM_SE                          # cycles during which the shader engines had waves
-                issue = v * 4.0 / NUM_SIMDS / busy
-                roof["pmc"]["valu_issue_frac_of_busy_cycles"] = round(issue, 4)
-                roof["frac"] = round(issue, 4)
-                roof["achieved"] = round(issue * peak_winst, 1)
-                roof["frac_is"] = "SQ_INSTS_VALU x 4 cycles / %d SIMDs over SQ_BUSY_CYCLES / %d shader engines: the share of busy cycles in which a SIMD's vector ALU issues" % (NUM_SIMDS, NUM_SE)
+                roof["pmc"]["valu_issue_frac_of_busy_cycles"] = round(v * 4.0 / NUM_SIMDS / busy, 4)
+                roof["pmc"]["busy_cycles_is"] = "SQ_INSTS_VALU x 4 / %d SIMDs over SQ_BUSY_CYCLES / %d shader engines; an SE counts busy while ANY of its waves lives, " \
+                                                "so the ratio can pass 1 when SEs drain at different times — kept as a cross-check, not as frac" % (NUM_SIMDS, NUM_SE)
             if "SQ_THREAD_CYCLES_VALU" in pmc and v > 0:
                 roof["pmc"]["exec_lanes_per_valu_inst"] = round(pmc["SQ_THREAD_CYCLES_VALU"][0] / v, 1)
             if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
                 roof["pmc"]["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"][0] / pmc["SQ_WAVE_CYCLES"][0], 3)
             if lane_inner and lane_leaf and roof["frac"]:
-                # useful share of the issued lane-slots, weighting the two sections by their executions x static length is not
-                # available live; the plain product with the inner-section fraction is the upper estimate
                 roof["useful_issue_frac_upper"] = round(roof["frac"] * max(lane_inner, lane_leaf), 4)
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             f, nf = pmc["FETCH_SIZE"]; w, nw = pmc["WRITE_SIZE"]
             per_launch = (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0                     # KB -> B; FETCH_SIZE doubled (gfx950 wide reads)
             roof["traffic"] = round(per_launch, 1)
-            roof["hbm"] = {"bytes_per_launch": round(per_launch, 1), "gbs": round(per_launch / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else None,
-                           "frac_of_hbm_peak": round(per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if avg_launch_s > 0 else None,
+            roof["hbm"] = {"bytes_per_launch": round(per_launch, 1), "gbs": round(per_launch / sec_launch_s / 1e9, 1) if sec_launch_s > 0 else None,
+                           "frac_of_hbm_peak": round(per_launch / sec_launch_s / 1e9 / HBM_PEAK_GBS, 4) if sec_launch_s > 0 else None,
                            "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / dispatches"}
-        if args.scaling == "strong":
-            workload = "%s %dx%d x %d spp FIXED frame dealt to %d GPU(s) in row stripes of %d (strong scaling%s)" % (
-                args.scene, width, height, spp, world, STRIPE_ROWS, ", BASELINE config 5" if args.config == "c5" else "")
-        else:
-            workload = "%s %dx%d, %d spp per GPU (frame = %d spp), rows dealt in stripes of %d" % (args.scene, width, height, base_spp, spp, STRIPE_ROWS)
-        workload += ", recursions 2 / spread 1, " + ("row index FIXED (v = idx / width)" if args.fix_row_index else "reference pixel mapping")
-        workload += ", intersector semantics: " + ("true closest hit (NoAccelerationIntersector, opt-out flag)" if args.true_closest_hit else
-                                                  "the reference's default OctTreeIntersector at 70 triangles per leaf (BVH + octree confirm step)")
         out = {
             "metric": "Mrays/s (whole node) + ms/frame, 1920x1080x64spp thai2.dae",
-            "value": round(total_rays / elapsed / 1e6, 2),
+            "value": main_group["value"],
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": main_group["ms_per_step"],
             "ms_per_step_median_rank0": round(sorted(step_ms)[len(step_ms) // 2], 3), "ms_per_step_min_rank0": round(min(step_ms), 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "scene": args.scene, "width": width, "height": height, "spp_per_gpu": spp if args.scaling == "strong" else base_spp,
-                       "frame_spp": spp, "seed": 1, "slices": slices, "parallelism": "row stripes x%d" % world, "gather": gather_kind},
+            "config": {"workload": main_group["workload"], "scene": args.scene, "width": width, "height": height, "spp_per_gpu": spp if args.scaling == "strong" else base_spp,
+                       "frame_spp": spp, "seed": 1, "slices": slices, "parallelism": "row stripes x%d" % world},
+            "gather_path": main_group["gather_path"], "rccl_ranks": main_group["rccl_ranks"], "gather_error": main_group["gather_error"],
+            "gather_ms_rank0": main_group["gather_ms_rank0"],
+            "hbm_allocated_bytes": main_group["hbm_allocated_bytes_rank0"],
             "primary_mrays_per_s": round(primary / elapsed / 1e6, 2),
-            "traced_mrays_per_s": round((total_rays - culled) / elapsed / 1e6, 2),
+            "traced_mrays_per_s": main_group["traced_mrays_per_s"],
             "traced_note": "value counts every primary sample (the reference's stats.rs:27 definition); traced_mrays_per_s leaves out the primary "
                            "samples of chunks the frustum culling skipped without tracing (%.1f %% of the primary samples)" % (100.0 * culled / max(primary, 1)),
             "rays_per_frame": {"primary": primary / args.steps, "bounce": bounce / args.steps, "shadow": shadow / args.steps, "primary_culled": culled / args.steps},
-            "gather_ms_rank0": round(sorted(gather_ms)[len(gather_ms) // 2], 3) if gather_ms else None,
             "other_semantics": other,
             "roofline": roof,
-            "accel": dict(acc, builder=("device LBVH (MI355RT_FLAG_DEVICE_LBVH)" if rt.bvh_build_info()["on_device"] else "host binned SAH"),
-                          device_build_ms=rt.bvh_build_info()["device_ms"]),
+            "accel": dict(acc, builder=("device LBVH (MI355RT_FLAG_DEVICE_LBVH)" if build_info["on_device"] else "host binned SAH"),
+                          device_build_ms=build_info["device_ms"]),
         }
+        out.update(groups)
+        if world == 1 and not args.no_dropin and args.scaling == "weak" and args.config == "c4":
+            d = dropin_measure(args, ge, pkg, scene, {}, "not collected in frame mode", full=False)
+            out["dropin"] = d
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ge, scene, width, height, args.fix_row_index)
         print(json.dumps(out), flush=True)
-    if native is not None:
-        native.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def dropin_mode(args, ge, pkg, scene, pmc, pmc_note):
+def dropin_measure(args, ge, pkg, scene, pmc, pmc_note, full):
     """The reference binary's loop (main.rs:197-207) at its defaults: thai2, 1024x768; one step = trace_frame_additive()
-    (50 rows x 1 sample = 51 200 primary rays) + get_tonemapped_pixels() (a fresh copy of the whole frame in host memory)."""
+    (50 rows x 1 sample = 51 200 primary rays) + get_tonemapped_pixels() (a fresh copy of the whole frame in host memory).
+    full: the whole --mode dropin line (args.steps steps); else the short `dropin` object of the frame-mode line."""
     import numpy as np
     import torch
     w, h = 1024, 768
+    steps, warmup = (args.steps, args.warmup) if full else (500, 50)
     extra = {"stripe_rows": args.stripe_rows} if args.stripe_rows > 0 else {}
     rt = pkg.create_raytracer_from_arrays(scene, pkg.DEFAULT_TRIANGLES_PER_LEAF, w, h, seed=1, **extra)
     buf = np.empty(w * h, np.uint32)
@@ -479,25 +606,25 @@ def dropin_mode(args, ge, pkg, scene, pmc, pmc_note):
         rt.get_tonemapped_pixels(buf)
         return n
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     primary = 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         primary += step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     # the two halves on their own
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         rt.trace_frame_additive()
     rt.last_counts()                                                   # waits for the device
-    trace_only = (time.perf_counter() - t1) / args.steps
+    trace_only = (time.perf_counter() - t1) / steps
     t2 = time.perf_counter()
-    for _ in range(min(args.steps, 200)):
+    for _ in range(min(steps, 200)):
         rt.get_tonemapped_pixels(buf)                                  # nothing dirty: the host copy alone
-    copy_only = (time.perf_counter() - t2) / min(args.steps, 200)
+    copy_only = (time.perf_counter() - t2) / min(steps, 200)
     # kernel time (HIP events around the fused launch) and rays per call
     rt.set_flags(pkg.FLAG_TIME_KERNELS)
     kms, rays, kcalls = 0.0, 0, 200
@@ -506,6 +633,28 @@ def dropin_mode(args, ge, pkg, scene, pmc, pmc_note):
         c = rt.last_counts()
         kms += c.trace_ms; rays += c.primary + c.bounce + c.shadow
     rt.set_flags(0)
+    avg_kernel_s = kms * 1e-3 / kcalls
+    cpu = None
+    if not args.no_cpu_baseline:
+        O = ge.load_oracle()
+        orc = O.Oracle(scene, w, h, seed=1)                              # the reference's default intersector (octree, 70 per leaf)
+        t = time.perf_counter(); calls = 0; prim = 0
+        budget, cap = (12.0, 400) if full else (4.0, 30)
+        while time.perf_counter() - t < budget and calls < cap:
+            prim += orc.trace_frame_additive(); orc.get_tonemapped_pixels(); calls += 1
+        dt = time.perf_counter() - t
+        model, phys, usable = cpu_model()
+        cpu = {"value": round(prim / dt, 1), "unit": "primary rays/s", "cores": 1, "kind": "port",
+               "sample": "%d calls of oracle_trace_frame_additive + oracle_get_tonemapped on 1 thread (%.1f s): the reference's loop is serial "
+                         "(mod.rs:80-117); octree oracle at 70 triangles per leaf" % (calls, dt),
+               "ms_per_step": round(dt / calls * 1e3, 2), "cpu_model": model, "physical_cores": phys, "build_flags": oracle_build_flags(ge)}
+    if not full:
+        return {"what": "the loop the reference binary runs (raytracer/src/main.rs:197-207) at its defaults: thai2 1024x768; one step = trace_frame_additive() "
+                        "(50 rows x 1 sample = 51 200 primary rays, ONE launch of fused_pass_kernel) + get_tonemapped_pixels() (whole frame as u32 in host memory)",
+                "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "primary_rays_per_s": round(primary / elapsed, 1),
+                "total_mrays_per_s": round(rays / kcalls / (elapsed / steps) / 1e6, 2), "fps": round(steps / elapsed, 1),
+                "ms_trace_frame_additive_only": round(trace_only * 1e3, 4), "ms_get_tonemapped_pixels_clean": round(copy_only * 1e3, 4),
+                "fused_kernel_ms": round(avg_kernel_s * 1e3, 4), "rays_per_call": rays / kcalls, "cpu_baseline": cpu}
     # the multi-launch wavefront rounds on the same calls, for the A/B
     os.environ["MI355RT_NO_FUSED"] = "1"
     for _ in range(20):
@@ -523,12 +672,11 @@ def dropin_mode(args, ge, pkg, scene, pmc, pmc_note):
     acc = rt.accel_stats()
     node_bytes = acc["node_bytes"] / max(acc["nodes"], 1)
     bytes_per_ray = node_bytes * c.nodes_visited / r1 + 48.0 * c.tris_tested / r1 + 96.0
-    avg_kernel_s = kms * 1e-3 / kcalls
     logical = rays / kcalls * bytes_per_ray / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     roof = {"bound": "latency", "kernel": "fused_pass_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(logical, 1), "frac": round(logical / HBM_PEAK_GBS, 4),
             "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "rays_per_call": rays / kcalls, "bytes_per_ray": round(bytes_per_ray, 1),
-            "note": "one launch of 800 waves (51 200 samples in 64-sample chunks, each wave takes its chunk through all 4 trace and 3 shade phases): "
-                    "the launch is a chain of dependent cache-latency-bound phases on a chip that is 1/10 full; achieved is the LOGICAL SURVEY 8d byte rate",
+            "note": "one launch of 1 600 waves (51 200 samples in 32-sample chunks, each wave takes its chunk through all 4 trace and 3 shade phases): "
+                    "the launch is a chain of dependent cache-latency-bound phases on a chip that is 1/5 full; achieved is the LOGICAL SURVEY 8d byte rate",
             "traffic": None, "pmc": {"note": pmc_note}}
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         f, nf = pmc["FETCH_SIZE"]; wv, nw = pmc["WRITE_SIZE"]
@@ -538,29 +686,20 @@ def dropin_mode(args, ge, pkg, scene, pmc, pmc_note):
     out = {
         "metric": "primary rays/s of the reference binary's loop: trace_frame_additive() + get_tonemapped_pixels(), thai2 1024x768 (main.rs:13-15,197-207)",
         "value": round(primary / elapsed, 1), "unit": "primary rays/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s 1024x768, 50 rows x 1 sample per call (51 200 primary rays), whole-frame u32 read-out into host memory per call" % args.scene,
                    "scene": args.scene, "width": w, "height": h, "seed": 1},
-        "fps": round(args.steps / elapsed, 1),
+        "fps": round(steps / elapsed, 1),
         "ms_trace_frame_additive_only": round(trace_only * 1e3, 4), "ms_get_tonemapped_pixels_clean": round(copy_only * 1e3, 4),
         "ms_per_step_wavefront_rounds": round(wavefront_ms, 4),
-        "total_mrays_per_s": round(rays / kcalls / (elapsed / args.steps) / 1e6, 2),
+        "total_mrays_per_s": round(rays / kcalls / (elapsed / steps) / 1e6, 2),
+        "hbm_allocated_bytes": rt.hbm_allocated_bytes(),
         "roofline": roof,
     }
-    if not args.no_cpu_baseline:
-        O = ge.load_oracle()
-        orc = O.Oracle(scene, w, h, seed=1)                              # the reference's default intersector (octree, 70 per leaf)
-        t = time.perf_counter(); calls = 0; prim = 0
-        while time.perf_counter() - t < 12.0 and calls < 400:
-            prim += orc.trace_frame_additive(); orc.get_tonemapped_pixels(); calls += 1
-        dt = time.perf_counter() - t
-        model, phys, usable = cpu_model()
-        out["cpu_baseline"] = {"value": round(prim / dt, 1), "unit": "primary rays/s", "cores": 1, "kind": "port",
-                               "sample": "%d calls of oracle_trace_frame_additive + oracle_get_tonemapped on 1 thread (%.1f s): the reference's loop is serial "
-                                         "(mod.rs:80-117); octree oracle at 70 triangles per leaf" % (calls, dt),
-                               "ms_per_step": round(dt / calls * 1e3, 2), "cpu_model": model, "physical_cores": phys, "build_flags": oracle_build_flags(ge)}
-    print(json.dumps(out), flush=True)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
 
 
 def cpu_baseline(ge, scene, width, height, fix_row_index=False):

@@ -138,6 +138,10 @@ typedef struct mi355rt_ray_counts {
     uint64_t leaf_execs;     /* only with MI355RT_FLAG_COUNT_STEPS: wave-level executions of the triangle section */
     double trace_ms;         /* summed HIP-event time of the trace kernels (MI355RT_FLAG_TIME_KERNELS) */
     double total_ms;         /* HIP-event time of the whole call on the handle's stream */
+    double trace_secondary_ms;        /* the part of trace_ms spent in launches of rounds >= 1 (reflection + shadow rays) */
+    uint64_t trace_secondary_launches;
+    double shader_clock_mhz; /* only with MI355RT_FLAG_COUNT_STEPS: the clock the trace waves actually ran at, sum of delta s_memtime over
+                              * sum of delta s_memrealtime (100 MHz) of all waves of the call's trace launches; 0 when not measured */
 } mi355rt_ray_counts;
 
 void mi355rt_default_config(mi355rt_config* cfg);
@@ -269,6 +273,10 @@ int mi355rt_synchronize(mi355rt_handle* h);
  * (mi355rt_synchronize waits for it).  librccl.so is loaded on first use. */
 #define MI355RT_COMM_ID_BYTES 128
 int mi355rt_comm_unique_id(uint8_t* id128);
+/* local, communication-free pre-check of mi355rt_comm_init (librccl.so loadable with every symbol, device bindable, no live
+ * communicator): the ranks should agree on this BEFORE any of them enters the collective mi355rt_comm_init, so that nobody
+ * blocks inside RCCL's bootstrap waiting for a rank that cannot join */
+int mi355rt_comm_available(mi355rt_handle* h);
 int mi355rt_comm_init(mi355rt_handle* h, const uint8_t* id128);
 int mi355rt_comm_gather_frame(mi355rt_handle* h, uint32_t root, uint32_t* host_out, size_t n);
 int mi355rt_comm_destroy(mi355rt_handle* h);

@@ -19,6 +19,7 @@ no CPU fallback here: if the shared library is missing, importing `lib()` raises
 """
 import ctypes as C
 import os
+import sys
 import time
 import weakref
 
@@ -78,6 +79,7 @@ class RayCounts(C.Structure):
         ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("trace_launches", C.c_uint64),
         ("inner_execs", C.c_uint64), ("leaf_execs", C.c_uint64),
         ("trace_ms", C.c_double), ("total_ms", C.c_double),
+        ("trace_secondary_ms", C.c_double), ("trace_secondary_launches", C.c_uint64), ("shader_clock_mhz", C.c_double),
     ]
 
     def as_dict(self):
@@ -133,6 +135,7 @@ ABI = [
     ("mi355rt_device_count", C.c_uint32, [_H]),
     ("mi355rt_synchronize", C.c_int, [_H]),
     ("mi355rt_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
+    ("mi355rt_comm_available", C.c_int, [_H]),
     ("mi355rt_comm_init", C.c_int, [_H, C.POINTER(C.c_uint8)]),
     ("mi355rt_comm_gather_frame", C.c_int, [_H, C.c_uint32, _U, C.c_size_t]),
     ("mi355rt_comm_destroy", C.c_int, [_H]),
@@ -153,6 +156,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "libmi355rt.so is not built (%s); run __graft_entry__.build() — there is no CPU fallback" % LIB_PATH)
+        # PyTorch ships its own copy of the HIP runtime.  A process that uses both (tests, bench.py: torch buffers and streams are
+        # handed to the library) must have torch's copy loaded FIRST, so that libmi355rt.so's libamdhip64 dependency resolves to
+        # the runtime already in the process instead of bringing /opt/rocm's as a second one.  Done here, once, for whoever has
+        # torch imported already; a host without torch (the C++ CLI, a Rust binary) never meets the question.
+        if "torch" in sys.modules:
+            try:
+                sys.modules["torch"].cuda.is_available()
+            except Exception:       # noqa: BLE001 — a CPU-only torch build
+                pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in ABI:
             fn = getattr(L, name)
@@ -309,6 +321,11 @@ class RayTracer:
         return int(lib().mi355rt_device_count(self._h))
 
     # --- one process per GPU: RCCL gather inside the library (include/mi355rt.h, mi355rt_comm_*)
+    def comm_available(self):
+        """(ok, error text): the local pre-check of comm_init; no communication"""
+        rc = lib().mi355rt_comm_available(self._h)
+        return rc == 0, "" if rc == 0 else (lib().mi355rt_last_error(self._h) or b"").decode()
+
     def comm_init(self, id128):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
         self._check(lib().mi355rt_comm_init(self._h, buf))

@@ -324,6 +324,12 @@ int mi355rt_comm_unique_id(uint8_t* id128)
     if (!comm_unique_id(id128, err)) { g_create_error = err; return MI355RT_E_HIP; }
     return MI355RT_OK;
 }
+int mi355rt_comm_available(mi355rt_handle* h)
+{
+    if (!h) return MI355RT_E_INVALID;
+    if (h->g->size() > 1) { h->r->last_error = "a device group gathers inside the process; RCCL communicators are for one-device handles"; return MI355RT_E_INVALID; }
+    return h->r->comm_available() ? MI355RT_OK : MI355RT_E_HIP;
+}
 int mi355rt_comm_init(mi355rt_handle* h, const uint8_t* id128)
 {
     if (!h || !id128) return MI355RT_E_INVALID;

@@ -70,6 +70,18 @@ bool comm_unique_id(uint8_t* id128, std::string& err)
 
 #define RCCL_TRY(expr) do { ncclResult_t r__ = (expr); if (r__ != ncclSuccess) { last_error = std::string(#expr) + ": " + a->GetErrorString(r__); return false; } } while (0)
 
+// Everything mi355rt_comm_init can fail on BEFORE it enters the collective ncclCommInitRank, checked locally and without
+// communication: the ranks agree on this answer first (stripes.py), so that no rank waits inside RCCL's bootstrap for a
+// peer that never got there.
+bool Renderer::comm_available()
+{
+    if (!bind()) return false;
+    RcclApi* a = rccl();
+    if (!a->error.empty()) { last_error = a->error; return false; }
+    if (comm_) { last_error = "communicator already initialised"; return false; }
+    return true;
+}
+
 bool Renderer::comm_init(const uint8_t* id128)
 {
     if (!bind()) return false;

@@ -98,6 +98,7 @@ struct DCounters {            // one set per render call, zeroed at its start
     unsigned long long primary_culled;            // primary samples in chunks the frustum culling skipped (never traced)
     unsigned long long t_first_end, t_last_end, t_sum_end, t_start, n_waves;   // COUNT mode: wave end times (s_memrealtime ticks, 100 MHz)
     unsigned long long lanes_inner, lanes_leaf, lanes_done, lane_samples;   // COUNT mode: where the lanes are at every loop iteration (summed lane counts; samples = iterations)
+    unsigned long long t_sum_cycles, t_sum_real;                                            // COUNT mode: summed s_memtime ticks (shader cycles) of the waves, against t_sum_end in s_memrealtime ticks
     unsigned long long refills, refill_passes, refill_rays;                    // COUNT mode: refill sections entered, passes through the assignment code, rays handed out
 };
 

@@ -73,6 +73,7 @@ bool DeviceGroup::render(uint32_t spp)
         counts_.primary_culled += c.primary_culled; counts_.nodes_visited += c.nodes_visited; counts_.tris_tested += c.tris_tested;
         counts_.trace_launches += c.trace_launches; counts_.inner_execs += c.inner_execs; counts_.leaf_execs += c.leaf_execs;
         counts_.trace_ms += c.trace_ms; counts_.total_ms = std::max(counts_.total_ms, c.total_ms);
+        counts_.trace_secondary_ms += c.trace_secondary_ms; counts_.trace_secondary_launches += c.trace_secondary_launches; counts_.shader_clock_mhz = std::max(counts_.shader_clock_mhz, c.shader_clock_mhz);
     }
     counts_from_render_ = true;
     return true;
@@ -91,6 +92,7 @@ bool DeviceGroup::last_counts(mi355rt_ray_counts& out)
         out.primary_culled += c.primary_culled; out.nodes_visited += c.nodes_visited; out.tris_tested += c.tris_tested;
         out.trace_launches += c.trace_launches; out.inner_execs += c.inner_execs; out.leaf_execs += c.leaf_execs;
         out.trace_ms += c.trace_ms; out.total_ms = std::max(out.total_ms, c.total_ms);
+        out.trace_secondary_ms += c.trace_secondary_ms; out.trace_secondary_launches += c.trace_secondary_launches; out.shader_clock_mhz = std::max(out.shader_clock_mhz, c.shader_clock_mhz);
     }
     return true;
 }

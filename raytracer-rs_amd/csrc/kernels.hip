@@ -301,8 +301,8 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
 {
     uint32_t acc_nodes = 0, acc_tris = 0, acc_ie = 0, acc_le = 0;
     uint32_t acc_li = 0, acc_ll = 0, acc_ld = 0, acc_it = 0, acc_rf = 0, acc_rp = 0, acc_rr = 0;       // COUNT only: lane census per iteration, refill statistics
-    unsigned long long t_begin = 0;
-    if (COUNT) t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_begin = 0, c_begin = 0;
+    if (COUNT) { t_begin = __builtin_amdgcn_s_memrealtime(); c_begin = __builtin_amdgcn_s_memtime(); }
 
     // wave-uniform work state: the chunk being handed out
     uint32_t w_chunk = 0u, w_next = 0u, w_nrad = 0u, w_ntot = 0u;
@@ -436,8 +436,9 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
             atomicAdd(&cs->lane_samples, (unsigned long long)acc_it); atomicAdd(&cs->refills, (unsigned long long)acc_rf); atomicAdd(&cs->refill_passes, (unsigned long long)acc_rp);
             atomicAdd(&cs->refill_rays, (unsigned long long)acc_rr);
             // load-balance diagnostics: when did this wave run out of work, relative to the first wave's start
-            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime(), c_end = __builtin_amdgcn_s_memtime();
             DCounters* c0 = &counters[0];
+            atomicAdd(&cs->t_sum_cycles, c_end - c_begin); atomicAdd(&cs->t_sum_real, t_end - t_begin);
             atomicMin(&c0->t_start, t_begin); atomicMin(&c0->t_first_end, t_end); atomicMax(&c0->t_last_end, t_end);
             atomicAdd(&c0->t_sum_end, t_end - t_begin); atomicAdd(&c0->n_waves, 1ull);
         }

@@ -546,6 +546,7 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
             for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); ev_pool_.push_back(ev); }
         }
         HIP_TRY(hipEventRecord(ev_pool_[ev_used_], tst));
+        ev_secondary_.resize(ev_pool_.size() / 2); ev_secondary_[ev_used_ / 2] = r > 0;
     }
     const void* in_q = r == 0 ? nullptr : sl.d_queue[(r - 1) & 1];
     const void* in_c = r == 0 ? nullptr : sl.d_chunk_counts[(r - 1) & 1];
@@ -637,6 +638,7 @@ bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
         c.bounce += s.bounce; c.shadow += s.shadow; c.primary_hits += s.primary_hits;
         c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
         c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs; c.primary_culled += s.primary_culled;
+        c.t_sum_cycles += s.t_sum_cycles; c.t_sum_real += s.t_sum_real;
     }
     counts = mi355rt_ray_counts{};
     counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
@@ -648,13 +650,16 @@ bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
         HIP_TRY(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
         counts.total_ms = ms;
     }
-    double tms = 0.0;
+    double tms = 0.0, sms = 0.0; uint64_t nsec = 0;
     for (size_t i = 0; i + 1 < ev_used_; i += 2) {           // MI355RT_FLAG_TIME_KERNELS: events around every trace / fused launch
         float t = 0.0f;
         HIP_TRY(hipEventElapsedTime(&t, ev_pool_[i], ev_pool_[i + 1]));
         tms += t;
+        if (i / 2 < ev_secondary_.size() && ev_secondary_[i / 2]) { sms += t; ++nsec; }
     }
-    counts.trace_ms = tms;
+    counts.trace_ms = tms; counts.trace_secondary_ms = sms; counts.trace_secondary_launches = nsec;
+    // s_memtime ticks are shader cycles, s_memrealtime ticks 10 ns: the clock the trace waves ran at (COUNT builds stamp both)
+    counts.shader_clock_mhz = c.t_sum_real ? (double)c.t_sum_cycles / (double)c.t_sum_real * 100.0 : 0.0;
     if (c.overflow) { last_error = "internal: ray queue overflow"; return false; }
     return true;
 }
@@ -748,6 +753,7 @@ uint32_t Renderer::trace_frame_additive()
         if (timed) {
             while (ev_used_ + 2 > ev_pool_.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { last_error = "hipEventCreate failed"; return 0; } ev_pool_.push_back(ev); }
             (void)hipEventRecord(ev_pool_[ev_used_], stream_);
+            ev_secondary_.resize(ev_pool_.size() / 2); ev_secondary_[ev_used_ / 2] = false;
         }
         hipError_t e = launch_fused_pass(stream_, num_cus_, mode_ == kModeConfirm, dscene_, cam, ps, max_level_nodes_, records_per_sample_, sl.d_queue[0], sl.d_queue[1],
                                          sl.d_hits, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_counters_);

@@ -40,6 +40,7 @@ public:
     bool finish_gather(uint32_t* host_out, size_t n);                   // root: slots -> frame (+ copy to the host when host_out != null)
     hipStream_t stream() const { return stream_; }
     hipEvent_t gather_event() const { return ev_gather_; }
+    bool comm_available();                                              // local pre-check of comm_init (no communication)
     bool comm_init(const uint8_t* id128);                               // RCCL communicator over the stripe ranks (collective)
     bool comm_gather(uint32_t root, uint32_t* host_out, size_t n);      // collective: grouped ncclSend / ncclRecv to the root, then finish_gather there
     void comm_destroy();
@@ -126,6 +127,7 @@ private:
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
     std::vector<hipEvent_t> ev_pool_;
     size_t ev_used_ = 0;
+    std::vector<uint8_t> ev_secondary_;  // per event pair: the launch traced secondary rays (rounds >= 1)
     std::vector<void*> allocs_;
     size_t alloc_bytes_ = 0;             // bytes behind allocs_ (scene, acceleration structures, film, row lists, cursors)
 

@@ -49,25 +49,48 @@ class FrameGather:
 class NativeGather:
     """The gather INSIDE libmi355rt.so (include/mi355rt.h, mi355rt_comm_*): grouped ncclSend / ncclRecv of the packed u32
     stripes to rank 0 on the handle's own stream, placement kernel on the root.  torch.distributed is used ONLY to hand
-    the 128-byte RCCL id from rank 0 to the other ranks and to agree that every rank got its communicator."""
+    the 128-byte RCCL id from rank 0 to the other ranks and to agree on the three verdicts below.
 
-    def __init__(self, pkg, rt, dist, rank, world):
+    No rank may enter the collective ncclCommInitRank unless every rank can: a rank that fails earlier would leave the
+    others blocked inside RCCL's bootstrap.  So the set-up is three agreed steps, each closed by an all_reduce(MIN):
+      1. every rank runs the library's LOCAL pre-check (mi355rt_comm_available: librccl.so loadable with all symbols, device
+         bindable, no live communicator); rank 0 also draws the unique id.  Any failure: nobody calls comm_init.
+      2. all ranks call comm_init (collective).
+      3. every rank reports what RCCL itself says about the communicator (ncclCommCount == world)."""
+
+    def __init__(self, pkg, rt, dist, rank, world, device="cuda"):
         self.rt = rt
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+        self.error = ""
+        self.ranks = 0
+        ok, err = rt.comm_available()
+        idt = torch.zeros(128, dtype=torch.uint8, device=device)
+        if ok and rank == 0:
+            try:
+                idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+            except Exception as e:      # noqa: BLE001 — agreed on below
+                ok, err = False, str(e)
+        if not self._agree(dist, ok, device):
+            raise RuntimeError("RCCL gather unavailable on some rank" + (": " + err if not ok else ""))
         dist.broadcast(idt, src=0)
-        ok = 1
+        ok = True
         try:
             rt.comm_init(bytes(idt.cpu().numpy().tobytes()))
-        except Exception as e:          # noqa: BLE001 — the failure is agreed on below, then raised on every rank
-            ok, self.error = 0, str(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
+        except Exception as e:          # noqa: BLE001 — agreed on below, then raised on every rank
+            ok, err = False, str(e)
+        if not self._agree(dist, ok, device):
             if ok:
                 rt.comm_destroy()
-            raise RuntimeError("mi355rt_comm_init failed on some rank" + (": " + self.error if not ok else ""))
+            raise RuntimeError("mi355rt_comm_init failed on some rank" + (": " + err if not ok else ""))
+        self.ranks = rt.comm_ranks()
+        if not self._agree(dist, self.ranks == world, device):
+            rt.comm_destroy()
+            raise RuntimeError("RCCL reports %d ranks in the communicator, expected %d" % (self.ranks, world))
+
+    @staticmethod
+    def _agree(dist, ok, device):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag[0]) == 1
 
     def gather(self):
         self.rt.comm_gather_frame(0, None)          # queued on the handle's stream; rt.synchronize() waits for it

@@ -56,3 +56,45 @@ def test_two_ranks_gather_the_single_gpu_frame():
     for p in procs:
         p.join(120)
     assert res == [(0, True), (1, True)]
+
+
+def _bench(argv, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                                  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_with_one_rank():
+    """`bench.py --gpus 1 --spawn`: the parent starts torch.distributed.run, which starts the one rank; the line carries the
+    three result groups (weak = the line itself, `strong`, `c5`), each with its gather fields, and the drop-in object."""
+    d = _bench(["--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "Mrays/s"
+    assert d["gather_path"] == "none" and d["rccl_ranks"] == 0 and d["gather_error"] is None
+    assert d["hbm_allocated_bytes"] > 0 and d["ms_per_step"] > 0
+    for g in ("strong", "c5"):
+        assert d[g]["scaling"] == "strong" and d[g]["ms_per_step"] > 0 and d[g]["gather_path"] == "none" and d[g]["gather_error"] is None
+    assert "3840x2160 x 256 spp" in d["c5"]["workload"]
+    assert d["c5"]["ms_per_step"] > 8 * d["strong"]["ms_per_step"]           # 16x the samples of the 1080p x 64 frame
+    assert d["dropin"]["ms_per_step"] > 0 and d["dropin"]["primary_rays_per_s"] > 1e6
+    r = d["roofline"]
+    assert r["secondary_launches"] > 0 and r["avg_secondary_launch_ms"] > 0 and r["clock_mhz_observed"] and 500 < r["clock_mhz_observed"] < 3000
+
+
+def test_bench_two_ranks_share_the_gpu_and_report_the_fallback():
+    """N = 2 rehearsal on the one GPU of the box (gloo, MI355RT_BENCH_SHARE_GPU): the library's RCCL path is asked for, RCCL
+    refuses two ranks on one device, every rank agrees on that, and the line SAYS so: gather_path torch_all_gather with a
+    non-null gather_error — in every result group."""
+    d = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-pmc", "--no-cpu-baseline", "--spp", "2"], {"MI355RT_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["gather_path"] in ("torch_all_gather", "library_rccl")
+    if d["gather_path"] == "torch_all_gather":
+        assert d["gather_error"] and d["rccl_ranks"] == 0
+    else:
+        assert d["gather_error"] is None and d["rccl_ranks"] == 2
+    assert d["gather_ms_rank0"] is not None

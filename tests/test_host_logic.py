@@ -101,3 +101,106 @@ def test_gather_slot_arithmetic_matches_the_placement_kernel(pkg):
                         assert s_ % world == r and (s_ // world) * stripe_rows + (y - s_ * stripe_rows) == local
                         seen.add(y)
                 assert seen == set(range(height))
+
+
+def test_bench_launches_its_own_ranks_before_touching_torch():
+    """`python bench.py --gpus N` without a launcher starts `torch.distributed.run` itself, as a child process, before the
+    parent has imported torch or the library (MI355RT_BENCH_DRY_SPAWN prints what would be started)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MI355RT_BENCH_DRY_SPAWN="1")
+    env.pop("WORLD_SIZE", None)
+    for argv, n in ((["--gpus", "8", "--steps", "5", "--warmup", "2"], 8), (["--gpus", "1", "--spawn"], 1)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        cmd = d["spawn"]
+        assert d["torch_imported"] is False and d["library_imported"] is False
+        assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+        assert cmd[cmd.index("--nproc-per-node") + 1] == str(n) and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+        tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+        assert "--spawn" not in tail and tail[:2] == ["--gpus", str(n)]
+    # under a launcher (WORLD_SIZE set) it is a rank, not a parent: a mismatch is refused instead of spawning again
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-pmc"], env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+class _FakeRt:
+    """stands in for a RayTracer in the set-up protocol of stripes.NativeGather (no GPU, no RCCL)"""
+
+    def __init__(self, available, init_ok, ranks):
+        self.available, self.init_ok, self.ranks = available, init_ok, ranks
+        self.calls = []
+
+    def comm_available(self):
+        self.calls.append("available")
+        return self.available, "" if self.available else "cannot load librccl.so"
+
+    def comm_init(self, _id):
+        self.calls.append("init")
+        if not self.init_ok:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+
+    def comm_ranks(self):
+        return self.ranks
+
+    def comm_destroy(self):
+        self.calls.append("destroy")
+
+
+class _FakePkg:
+    @staticmethod
+    def comm_unique_id():
+        return bytes(range(128))
+
+
+def _native_worker(rank, world, port, scenario, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    ge.load_package()
+    st = importlib.import_module("raytracer_rs_amd.stripes")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rt = {"rank1_cannot_load": _FakeRt(rank != 1, True, world), "rank0_init_fails": _FakeRt(True, rank != 0, world),
+          "wrong_count": _FakeRt(True, True, 1 if rank == 1 else world), "all_good": _FakeRt(True, True, world)}[scenario]
+    err = None
+    try:
+        ng = st.NativeGather(_FakePkg, rt, dist, rank, world, device="cpu")
+        assert ng.ranks == world
+    except RuntimeError as e:
+        err = str(e)
+    q.put((rank, err, rt.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["rank1_cannot_load", "rank0_init_fails", "wrong_count", "all_good"])
+def test_native_gather_setup_is_agreed_step_by_step(scenario):
+    """No rank enters the collective comm_init unless EVERY rank passed the local pre-check (a rank that cannot load
+    librccl.so must not leave the others waiting inside RCCL's bootstrap); a failing init or a communicator of the wrong
+    size is raised on every rank together, and ranks that did get a communicator give it back."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    errs = [e for _, e, _ in res]
+    calls = [c for _, _, c in res]
+    if scenario == "all_good":
+        assert errs == [None, None] and calls == [["available", "init"]] * 2
+    elif scenario == "rank1_cannot_load":
+        assert all(e and "unavailable" in e for e in errs)
+        assert all("init" not in c for c in calls)                          # nobody entered the collective
+    elif scenario == "rank0_init_fails":
+        assert all(e and "comm_init failed" in e for e in errs)
+        assert calls[0] == ["available", "init"] and calls[1] == ["available", "init", "destroy"]
+    else:
+        assert all(e and "expected 2" in e for e in errs)
+        assert all(c == ["available", "init", "destroy"] for c in calls)
