@@ -88,6 +88,8 @@ struct DPass {
     uint32_t pull_group;      // pull mode 4: consecutive chunks handed out per atomic
     uint32_t pull_mode;       // work distribution: 4 = cursors (default), 2 = static striding, 0 = one cursor
     uint32_t list_cap;        // shade kernel: LDS hit-list entries per wave (max radiance rays per chunk)
+    uint32_t tail_chunks;     // trace kernel: the last tail_chunks chunks of every cursor's sequence are handed out in parts (host: chunks per wave; the launcher scales it by the waves per cursor)
+    uint32_t tail_split_shift; // log2 of the parts a tail chunk is handed out in (0: whole chunks everywhere)
 };
 
 struct DCounters {            // one set per render call, zeroed at its start

@@ -91,10 +91,18 @@ __device__ __forceinline__ uint32_t global_wave_id() { return blockIdx.x * kWave
 //   mode 0: one cursor (kept for the A/B in profiles/r01_notes.md).
 // Tried and dropped: a relaxed agent-scope load in front of the atomic (2.5x slower), 3/4 static + a
 // dynamic rest, several chunks per pull, draining more than 8 cursors, heaviest-chunks-first order.
-constexpr uint32_t kCursorStride = 16384;   // u32 words between cursors (64 KiB): atomics to nearby lines serialise on one memory channel
-struct PullState { bool first = true; uint32_t shard = 0u, tries = 0u, left = 0u; };
+constexpr uint32_t kCursorStride = kCtrlWordsPerRound / kMaxCursors;   // u32 words between cursors (64 KiB): atomics to nearby lines serialise on one memory channel
+static_assert(kCursorStride == 16384 && kShadeCursorOffset == 2 * kConfirmCursorOffset, "cursor layout (device_types.hpp) and the reset loop of resolve_kernel");
+struct PullState { bool first = true; uint32_t shard = 0u, tries = 0u, left = 0u, part = 0xFFFFFFFFu; };
+constexpr uint32_t kWholeChunk = 0xFFFFFFFFu;
 
-__device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, uint32_t ncursors, uint32_t group, PullState& st, uint32_t& chunk)
+// tail / split (trace kernels only; 0 / 1 elsewhere): the LAST `tail` chunks of every cursor's sequence are handed out in `split`
+// parts (st.part = 0 .. split-1; kWholeChunk otherwise), several waves sharing a chunk.  A persistent launch ends when its slowest
+// wave does, and with whole chunks the waves run out of work up to ~1.5 chunk durations apart — a fifth of a launch of 8 chunks per
+// wave (one rank's share of a strong-scaled frame), a tenth of a full-size one (profiles/r03_notes.md).  Splitting only the tail keeps
+// the per-pull cost (count load, culling test, a colder start) off the bulk of the chunks.
+__device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, uint32_t ncursors, uint32_t group, PullState& st, uint32_t& chunk,
+                                           uint32_t tail = 0u, uint32_t split_shift = 0u)
 {
     if (mode == 4u) {
         if (st.first) { st.first = false; st.shard = global_wave_id() % ncursors; }
@@ -103,8 +111,17 @@ __device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, u
         while (st.tries < max_tries) {
             uint32_t v = 0u;
             if (lane_id() == 0) v = atomicAdd(&cursor[(size_t)st.shard * kCursorStride], 1u);
-            const uint32_t c = (st.shard + bcast_first(v) * ncursors) * group;
-            if (c < nchunks) { chunk = c; st.left = group - 1u; return true; }
+            v = bcast_first(v);
+            if (tail != 0u && group == 1u) {
+                const uint32_t len = st.shard < nchunks ? (nchunks - st.shard + ncursors - 1u) / ncursors : 0u;     // chunks of this cursor
+                const uint32_t head = len - (tail < len ? tail : len);
+                uint32_t j = v; st.part = kWholeChunk;
+                if (v >= head) { const uint32_t jj = v - head; j = head + (jj >> split_shift); st.part = jj & ((1u << split_shift) - 1u); }
+                if (j < len) { chunk = st.shard + j * ncursors; return true; }
+            } else {
+                const uint32_t c = (st.shard + v * ncursors) * group;
+                if (c < nchunks) { chunk = c; st.left = group - 1u; return true; }
+            }
             st.shard = (st.shard + 1u) % ncursors;      // dry for good
             ++st.tries;
         }
@@ -262,10 +279,12 @@ __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, 
 
 // ---- ray records: two float4 planes q0[], q1[] per queue (32 B per ray) --------------------------------------------
 //   radiance ray: q0 = { o.xyz, d.x },    q1 = { d.y, d.z, light-term slot of its sample, level << 4 | tree node << 8 }
-//   shadow ray:   q0 = { hp.xyz, term },  q1 = { c.xyz, - }   hp: the shaded hit point, term: float index of its light
-//                 term in slot_L, c: the finished term (stored when the ray turns out unblocked).  The ray itself is
-//                 rebuilt from hp and the light by the kernel that traces it — the expressions of mod.rs:215, 224-225
-//                 in the order shade() evaluates them, so the floats are the ones the reference traces.
+//   shadow ray:   q0 = { hp.xyz, term },  q1 unused   hp: the shaded hit point, term: float index of its light term in slot_L.
+//                 The kernel that shades writes the finished term into slot_L at once — OPTIMISTICALLY: most shadow rays reach
+//                 the light — and whoever finds the ray BLOCKED (mod.rs:226-232) puts the zero back (store_blocked): the
+//                 unblocked majority costs no load and no store after the trace.  The ray itself is rebuilt from hp and the
+//                 light by the kernel that traces it — the expressions of mod.rs:215, 224-225 in the order shade()
+//                 evaluates them, so the floats are the ones the reference traces.
 // (pixel, sample number) of a sample — the reflection sampler's hash inputs — live in ps.slot_ps, per light-term slot.
 __device__ __forceinline__ void shadow_ray_of(const DScene& sc, const DPass& ps, const float4 q0, f3& o, f3& d)
 {
@@ -277,12 +296,15 @@ __device__ __forceinline__ void shadow_ray_of(const DScene& sc, const DPass& ps,
     o = add3(hp, vscale(l, 0.01f)); d = l;                                      // mod.rs:224-225
 }
 
-// a shadow ray that is not blocked (it hit nothing, or nothing in (0.01, 1)): store the light term it carries
-__device__ __forceinline__ void store_unblocked(const DPass& ps, uint32_t r, const float4* __restrict__ in_q, float* __restrict__ slot_L)
+// a shadow ray that IS blocked (its intersector hit lies in (0.01, 1), mod.rs:226-232): the light term the shade kernel wrote
+// optimistically does not count — back to black (mod.rs:232 `continue`)
+__device__ __forceinline__ void store_blocked(float* __restrict__ slot_L, uint32_t term)
 {
-    const float4 q0 = in_q[r], q1 = in_q[ps.qstride + r];
-    float* dst = slot_L + __float_as_uint(q0.w);
-    dst[0] = q1.x; dst[1] = q1.y; dst[2] = q1.z;
+    // three dword stores of ONE zero register (the compiler's own choice is a dwordx3 store of three zero registers: in the
+    // trace kernels, which sit at the 64-VGPR limit of 8 waves per SIMD, those two extra registers are a scratch spill)
+    float* dst = slot_L + term;
+    const float zero = 0.0f;
+    asm volatile("global_store_dword %0, %1, off\n\tglobal_store_dword %0, %1, off offset:4\n\tglobal_store_dword %0, %1, off offset:8" : : "v"(dst), "v"(zero) : "memory");
 }
 
 // ---- trace: closest hit of every ray of a round --------------------------------------------------
@@ -311,7 +333,6 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
     // lane state
     RayState rs;
     uint32_t rec = 0;                                // radiance: hit-record index; shadow: float index into slot_L (both < 2^32)
-    // a shadow ray never touches rs.t / rs.u / rs.v (only radiance rays record a hit): they carry its light term
     ray_init(rs, mk3(0, 0, 0), mk3(0, 0, 1), false, sc.root);
     rs.node = kNodeIdle;
     stack[0] = kNodeFin;                             // sentinel row of this lane's stack column (traverse.hpp, pop_or_finish)
@@ -337,16 +358,15 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     if (rs.occ < 0) {                                           // radiance ray
                         st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), hit ? rs.prim : kMiss);
                         if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
-                    } else if (!(hit && rs.t > 0.01f && rs.t < 1.0f)) {          // shadow ray, not blocked (mod.rs:226-232)
-                        store_unblocked(ps, rec, in_q, slot_L);
+                    } else if (hit && rs.t > 0.01f && rs.t < 1.0f) {              // shadow ray (rec: its term), blocked (mod.rs:226-232)
+                        store_blocked(slot_L, rec);
                     }
                 } else
                 if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
                     st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), rs.prim);     // 4 B for every ray, the 16 B record only for hits
                     if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
-                } else if (rs.occ != 1) {                              // not blocked, mod.rs:232
-                    float* dst = slot_L + rec;
-                    dst[0] = rs.t; dst[1] = rs.u; dst[2] = rs.v;
+                } else if (rs.occ == 1) {                              // blocked, mod.rs:232
+                    store_blocked(slot_L, rec);
                 }
             }
         }
@@ -358,7 +378,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     if (!w_pull.first) { exhausted = true; break; }
                     w_pull.first = false; c = single_chunk;
                 }
-                else if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c)) { exhausted = true; break; }
+                else if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c, ps.tail_chunks, ps.tail_split_shift)) { exhausted = true; break; }
                 // bcast_first: these are wave-uniform by construction; saying so keeps them in SGPRs
                 w_chunk = bcast_first(c); w_next = 0u;
                 if (PRIMARY) {
@@ -369,6 +389,11 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                 }
                 else if (SINGLE) { w_nrad = single_nrad; w_ntot = single_nrad + single_nshadow; }      // from the shade phase, in registers
                 else { const uint2 n = in_counts[w_chunk]; w_nrad = bcast_first(n.x); w_ntot = w_nrad + bcast_first(n.y); }
+                if (!SINGLE && w_pull.part != kWholeChunk) {       // a part of a tail chunk: rays [part * per, (part + 1) * per) of it, per a multiple of 64
+                    const uint32_t per = ((w_ntot + (64u << ps.tail_split_shift) - 1u) >> (6u + ps.tail_split_shift)) << 6;
+                    w_next = bcast_first(min(w_pull.part * per, w_ntot));
+                    w_ntot = bcast_first(min(w_next + per, w_ntot));
+                }
                 continue;
             }
             const uint32_t avail = w_ntot - w_next;
@@ -378,7 +403,6 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                 const uint32_t i = w_next + rank;
                 f3 o, d;
                 bool shadow = false;
-                float4 sh_L4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (PRIMARY) {
                     uint32_t pixel, sampleno;
                     primary_sample(cam, ps, film_n, w_chunk * ps.chunk + i, pixel, sampleno, o, d);
@@ -392,18 +416,15 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     const char* __restrict__ p1 = (const char*)(in_q + ps.qstride);
                     const float4 r0 = ld4<0>((const float4*)(p0 + (r << 4)));
                     float4 r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (!(CONFIRM && shadow)) r1 = ld4<0>((const float4*)(p1 + (r << 4)));    // CONFIRM: a shadow ray's second plane is the confirm step's business
+                    if (!shadow) r1 = ld4<0>((const float4*)(p1 + (r << 4)));                      // a shadow record has no second plane
                     rec = r;
                     if (shadow) {
                         shadow_ray_of(sc, ps, r0, o, d);
-                        if (!CONFIRM) {                 // keep what the finish needs in registers: no load when the ray ends
-                            sh_L4 = r1;
-                            rec = __float_as_uint(r0.w);           // float index of its light term in slot_L (shade kernel)
-                        }
+                        // a shadow ray whose verdict is reached right here (true-closest semantics; one-leaf octrees) needs its term, not its record
+                        if (!CONFIRM || sc.oct_single_leaf) rec = __float_as_uint(r0.w);           // float index of its light term in slot_L (shade kernel)
                     } else { o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
                 }
                 ray_init(rs, o, d, shadow, sc.root);
-                if (!CONFIRM && shadow) { rs.t = sh_L4.x; rs.u = sh_L4.y; rs.v = sh_L4.z; }
             }
             w_next += min((uint32_t)__popcll(idle), avail);
             idle = __ballot(rs.node == kNodeIdle);
@@ -486,8 +507,8 @@ __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera
             if (i < n_rad) {
                 ps.hit_prim[r] = prim;
                 if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
-            } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {          // not blocked, mod.rs:226-232
-                store_unblocked(ps, (uint32_t)r, in_q, slot_L);
+            } else if (prim != kMiss && t > 0.01f && t < 1.0f) {              // blocked, mod.rs:226-232
+                store_blocked(slot_L, ((const uint32_t*)in_q)[4ull * r + 3u]);
             }
         }
     }
@@ -510,11 +531,13 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
                                                const float4* __restrict__ in_q, float4* __restrict__ hits, float* __restrict__ slot_L, const uint32_t* __restrict__ film_n)
 {
     f3 o, d;
+    float term_bits = 0.0f;
     if (PRIMARY) {
         uint32_t pixel, sampleno;
         primary_sample(cam, ps, film_n, sample_index, pixel, sampleno, o, d);
     } else {
         const float4 r0 = ld4<3>(&in_q[r]);
+        term_bits = r0.w;
         if (shadow) shadow_ray_of(sc, ps, r0, o, d);
         else { const float4 r1 = ld4<3>(&in_q[ps.qstride + r]); o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
     }
@@ -529,8 +552,8 @@ __device__ __forceinline__ void confirm_record(const DScene& sc, const DCamera& 
             ps.hit_prim[r] = prim;
             if (prim != kMiss) hits[r] = make_float4(t, u, v, __uint_as_float(prim));
         }
-    } else if (!(prim != kMiss && t > 0.01f && t < 1.0f)) {               // not blocked, mod.rs:226-232
-        store_unblocked(ps, r, in_q, slot_L);
+    } else if (prim != kMiss && t > 0.01f && t < 1.0f) {                   // blocked, mod.rs:226-232
+        store_blocked(slot_L, __float_as_uint(term_bits));
     }
 }
 
@@ -552,7 +575,6 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
         const bool valid = i < n_tot;
         const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
         const bool hit = valid && ld1<3>(&ps.hit_prim[r]) != kMiss;
-        if (!PRIMARY && valid && !hit && i >= n_rad) store_unblocked(ps, r, in_q, slot_L);
         uint32_t n_new;
         const uint32_t pos = wave_append(hit, cnt, n_new);
         if (hit) list[pos] = i;
@@ -592,8 +614,7 @@ __global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel
             const bool valid = i < n_tot;
             const uint32_t r = valid ? (uint32_t)record_index(ps, chunk, i, n_rad) : 0u;
             const bool hit = valid && ld1<3>(&ps.hit_prim[r]) != kMiss;
-            if (!PRIMARY && valid && !hit && i >= n_rad) store_unblocked(ps, r, in_q, slot_L);
-            uint32_t n_new;
+                uint32_t n_new;
             const uint32_t pos = wave_append(hit, cnt, n_new);
             if (hit) { list_r[pos] = r | (i >= n_rad ? 0x80000000u : 0u); if (PRIMARY) list_s[pos] = chunk * ps.chunk + i; }
             __builtin_amdgcn_wave_barrier();
@@ -683,6 +704,9 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                 for (uint32_t k = (uint32_t)lane; k < total / 4u; k += 64u) st4<2>(&z4[k], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 for (uint32_t k = (total & ~3u) + (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
             }
+            // the terms of this chunk's level-0 nodes are written below, by other lanes of this wave, to the addresses just zeroed:
+            // the zeroes must have left the wave first (workgroup scope = wait for the stores, nothing is flushed)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t out_front = 0u, out_back = 0u, dropped = 0u;
@@ -745,7 +769,8 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                     const size_t r = base + (ps.region - 1u - oi);
                     const uint32_t term = 3u * ((node * sc.nlights + li) * ps.nslots + slot);             // float index in slot_L (< 2^32: renderer.cpp)
                     st4<2>(&out_q[r], make_float4(hp.x, hp.y, hp.z, __uint_as_float(term)));
-                    st4<2>(&out_q[ps.qstride + r], make_float4(c.x, c.y, c.z, 0.0f));
+                    float* dst = slot_L + term;                    // optimistic: whoever finds the shadow ray blocked zeroes it again (store_blocked)
+                    dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
                 }
             }
             // ---- reflection rays, mod.rs:146-158 + 178-196
@@ -860,8 +885,12 @@ __device__ f3 node_radiance(const float* __restrict__ L, const DPass& ps, uint32
 template <uint32_t kResolveLanes>
 __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, uint32_t nlights, const float* __restrict__ slot_L,
                                                      const uint32_t* __restrict__ sample_slot,
-                                                     float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
+                                                     float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color, uint32_t* ctrl)
 {
+    // last kernel of a pass: leave the pass's work cursors zeroed for the next one (960 words; a 20 MiB memset otherwise)
+    if (ctrl != nullptr && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < kMaxRounds * kMaxCursors * 3u; i += blockDim.x)
+            ctrl[(size_t)(i / (kMaxCursors * 3u)) * kCtrlWordsPerRound + (size_t)((i / 3u) % kMaxCursors) * kCursorStride + (i % 3u) * kConfirmCursorOffset] = 0u;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = gid % kResolveLanes;
     const bool live = gid / kResolveLanes < ps.npix;
@@ -1143,7 +1172,11 @@ static hipError_t launch_trace_variant(hipStream_t stream, int num_cus, int bloc
     int use_per_cu = per_cu;
     if (blocks_per_cu_cap > 0 && blocks_per_cu_cap < use_per_cu) use_per_cu = blocks_per_cu_cap;      // leave room for another stream's kernels
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= per_cu) use_per_cu = v; }   // occupancy experiment
-    hipLaunchKernelGGL((trace_kernel<P, C, F>), dim3((unsigned)(num_cus * use_per_cu)), dim3(kBlock), lds, stream, sc, cam, ps,
+    // tail of every cursor's chunk sequence that is handed out in parts (pull_chunk): ps.tail_chunks comes in as "chunks per WAVE"
+    DPass pt = ps;
+    const uint32_t waves_per_cursor = ((uint32_t)(num_cus * use_per_cu) * kWavesPerBlock + ps.ncursors - 1u) / ps.ncursors;
+    pt.tail_chunks = (ps.pull_mode == 4u && ps.pull_group == 1u && ps.tail_split_shift != 0u) ? ps.tail_chunks * waves_per_cursor : 0u;
+    hipLaunchKernelGGL((trace_kernel<P, C, F>), dim3((unsigned)(num_cus * use_per_cu)), dim3(kBlock), lds, stream, sc, cam, pt,
                        (const float4*)in_q, (const uint2*)in_counts, (float4*)hits, cursor, slot_L, film_n, counters);
     return hipGetLastError();
 }
@@ -1193,13 +1226,13 @@ hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk
 }
 
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
-                          float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color)
+                          float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color, uint32_t* ctrl)
 {
     const uint32_t spp = ps.npix ? ps.nsamples / ps.npix : 1u;
     uint32_t lanes = spp <= 32u ? 2u : (spp <= 96u ? 4u : 8u);
     if (const char* e = getenv("MI355RT_RESOLVE_LANES")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) lanes = (uint32_t)v; }
     dim3 block(256), grid((unsigned)(((size_t)ps.npix * lanes + 255) / 256));
-#define MI355RT_RESOLVE_ARGS grid, block, 0, stream, ps, width, nlights, slot_L, sample_slot, film_sum, film_sumsq, film_n, debug_color
+#define MI355RT_RESOLVE_ARGS grid, block, 0, stream, ps, width, nlights, slot_L, sample_slot, film_sum, film_sumsq, film_n, debug_color, ctrl
     switch (lanes) {
         case 1: hipLaunchKernelGGL(resolve_kernel<1>, MI355RT_RESOLVE_ARGS); break;
         case 2: hipLaunchKernelGGL(resolve_kernel<2>, MI355RT_RESOLVE_ARGS); break;

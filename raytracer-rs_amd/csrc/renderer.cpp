@@ -260,6 +260,8 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_owned_rows_, owned_rows.data(), owned_rows.size() * 4)) return bail();
     if (!upload(d_tmp_rows_, nullptr, 64 * 4)) return bail();
     if (!upload(d_counters_, nullptr, sizeof(DCounters) * kShards)) return bail();
+    if (hipHostMalloc((void**)&h_counters_, sizeof(DCounters) * kShards, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return false; }
+    std::memset(h_counters_, 0, sizeof(DCounters) * kShards);
     slices_[0].stream = stream_;
     if (hipStreamCreateWithFlags(&trace_stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
     for (uint32_t i = 0; i < kMaxSlices; ++i) {
@@ -301,6 +303,7 @@ Renderer::~Renderer()
     if (trace_stream_) { (void)hipStreamSynchronize(trace_stream_); (void)hipStreamDestroy(trace_stream_); }
     for (void* p : allocs_) (void)hipFree(p);
     if (h_ldr_) (void)hipHostFree(h_ldr_);
+    if (h_counters_) (void)hipHostFree(h_counters_);
     comm_destroy();
     if (d_gather_) (void)hipFree(d_gather_);
     if (ev_tonemap_) (void)hipEventDestroy(ev_tonemap_);
@@ -507,6 +510,8 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     ps.pull_mode = 4u;                  // 64 interleaved cursors (see pull_chunk in kernels.hip)
     if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
     ps.pull_group = 1; if (const char* e = getenv("MI355RT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.pull_group = (uint32_t)v; }
+    ps.tail_chunks = 2; if (const char* e = getenv("MI355RT_TAIL_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 64) ps.tail_chunks = (uint32_t)v; }
+    ps.tail_split_shift = 2; if (const char* e = getenv("MI355RT_TAIL_SPLIT")) { int v = atoi(e); if (v >= 0 && v <= 4) ps.tail_split_shift = (uint32_t)v; }
     ps.ncursors = 64; if (const char* e = getenv("MI355RT_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxCursors) ps.ncursors = (uint32_t)v; }
 }
 
@@ -524,7 +529,9 @@ bool Renderer::pass_begin(PassRun& run, Slice& sl, const uint32_t* d_rows, uint3
     describe_pass(run.ps, sl, d_rows, row0, row_wrap, npix, nsamples, chunk_, explicit_sample, epixel, esample);
     run.cam = device_camera();
     run.rounds = cfg.recursions + 2;
-    HIP_TRY(hipMemsetAsync(sl.d_ctrl, 0, kMaxRounds * kCtrlWordsPerRound * 4, sl.stream));
+    // the work cursors: zeroed at creation and again by the resolve kernel of every pass that ran to its end (pass_end)
+    if (!sl.ctrl_clean) HIP_TRY(hipMemsetAsync(sl.d_ctrl, 0, kMaxRounds * kCtrlWordsPerRound * 4, sl.stream));
+    sl.ctrl_clean = false;
     run.live = true;
     return true;
 }
@@ -605,7 +612,8 @@ bool Renderer::pass_end(PassRun& run)
 {
     if (!run.live) return true;
     Slice& sl = *run.sl;
-    HIP_TRY(launch_resolve(sl.stream, run.ps, cfg.width, nlights_, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_));
+    HIP_TRY(launch_resolve(sl.stream, run.ps, cfg.width, nlights_, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_debug_color_, sl.d_ctrl));
+    sl.ctrl_clean = true;
     run.live = false;
     return true;
 }
@@ -632,9 +640,10 @@ bool Renderer::begin_call()
 // Download the device counters of the call that just ended (the stream must be idle).
 bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
 {
-    DCounters shard[kShards], c{};
-    HIP_TRY(hipMemcpy(shard, d_counters_, sizeof shard, hipMemcpyDeviceToHost));
-    for (const DCounters& s : shard) {
+    DCounters c{};
+    const DCounters* shard = h_counters_;          // pinned; filled by the asynchronous copy queue_counts_copy() put behind the call's kernels
+    for (uint32_t i = 0; i < kShards; ++i) {
+        const DCounters& s = shard[i];
         c.bounce += s.bounce; c.shadow += s.shadow; c.primary_hits += s.primary_hits;
         c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
         c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs; c.primary_culled += s.primary_culled;
@@ -664,6 +673,13 @@ bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
     return true;
 }
 
+// the call's device counters -> the pinned host mirror, stream-ordered behind the call's kernels (one wait serves both)
+bool Renderer::queue_counts_copy()
+{
+    HIP_TRY(hipMemcpyAsync(h_counters_, d_counters_, sizeof(DCounters) * kShards, hipMemcpyDeviceToHost, stream_));
+    return true;
+}
+
 bool Renderer::end_call(uint64_t primary)
 {
     for (uint32_t i = 1; i < active_slices_; ++i) {          // join the slices on the main stream
@@ -672,6 +688,7 @@ bool Renderer::end_call(uint64_t primary)
     }
     active_slices_ = 1;
     HIP_TRY(hipEventRecord(ev_end_, stream_));
+    if (!queue_counts_copy()) return false;
     HIP_TRY(hipStreamSynchronize(stream_));
     return fetch_counts(primary, true);
 }
@@ -763,6 +780,7 @@ uint32_t Renderer::trace_frame_additive()
     }
     current_row = win.next_row;
     mark_dirty_window(win.first, win.total);
+    if (!queue_counts_copy()) return 0;
     counts_pending_ = true; pending_primary_ = (uint64_t)win.total * cfg.width;
     return 50u * cfg.width;
 }

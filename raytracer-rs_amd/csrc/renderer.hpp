@@ -89,6 +89,7 @@ private:
         std::vector<uint32_t> rows;              // this slice's rows (host copy of d_rows)
         uint32_t* d_rows = nullptr;
         uint32_t* d_ctrl = nullptr;              // per round: chunk cursors
+        bool ctrl_clean = true;                  // the cursors are zero (creation, or the last pass's resolve kernel left them so)
         void* d_queue[2] = { nullptr, nullptr };
         uint32_t* d_chunk_counts[2] = { nullptr, nullptr };   // rays per chunk in each queue
         void* d_hits = nullptr;
@@ -115,6 +116,7 @@ private:
     bool begin_call();
     bool end_call(uint64_t primary);
     bool fetch_counts(uint64_t primary, bool timed_call);
+    bool queue_counts_copy();
     void mark_dirty_window(uint32_t first, uint32_t total);
     DCamera device_camera() const;
     void collect_cull_boxes();
@@ -144,6 +146,7 @@ private:
     bool counts_pending_ = false;        // the last call was an asynchronous 50-row frame: counters not fetched yet
     uint64_t pending_primary_ = 0;
     DCounters* d_counters_ = nullptr;
+    DCounters* h_counters_ = nullptr;    // pinned host mirror (queue_counts_copy)
     float* d_debug_color_ = nullptr;
     static constexpr uint32_t kMaxSlices = 8;
     Slice slices_[kMaxSlices];

@@ -1,0 +1,34 @@
+"""Rank 0's share of the strong-scaled headline frame (thai2 1920x1080x64 over N ranks, 2-row stripes) and the N = 1 frame on ONE GPU,
+under environment-variable variants of the library (read at create time).  usage: share_sweep.py VAR=a,b,c [VAR2=...] [--worlds 8,1]"""
+import itertools, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+import importlib
+sio = importlib.import_module("raytracer_rs_amd.scene_io")
+sc = sio.load_scene_file(os.path.join(ge.SCENES, "thai2.scene"))
+worlds = [8, 1]
+sweeps = []
+for a in sys.argv[1:]:
+    if a.startswith("--worlds"):
+        worlds = [int(x) for x in a.split("=", 1)[1].split(",")]
+    else:
+        k, v = a.split("=", 1)
+        sweeps.append([(k, x) for x in v.split(",")])
+for combo in itertools.product(*sweeps) if sweeps else [()]:
+    for k, v in combo:
+        if v == "-":
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    out = []
+    for world in worlds:
+        rt = pkg.create_raytracer_from_arrays(sc, 70, 1920, 1080, seed=1, stripe_rows=2, stripe_rank=0, stripe_world=world)
+        ts = []
+        for it in range(7):
+            rt.film.clear()
+            t = time.time(); c = rt.render(64); ts.append(time.time() - t)
+        ts.sort()
+        out.append("N=%d share: min %.3f med %.3f ms (gpu %.3f)" % (world, ts[0] * 1e3, ts[len(ts) // 2] * 1e3, c.total_ms))
+        del rt
+    print(" ".join("%s=%s" % kv for kv in combo) or "default", "|", " | ".join(out), flush=True)
