@@ -184,15 +184,32 @@ void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, 
                            + (scene.mx[2] - scene.mn[2]) * (scene.mx[2] - scene.mn[2]));
     float pad = std::max(diag * 2e-5f, 1e-6f);
 
-    // breadth-first numbering of inner nodes; leaves get triangle ranges in visit order
+    // Numbering of the inner nodes = their place in memory.  The first nodes are staged in LDS by the trace kernel (kernels.hip,
+    // node cache): the numbering is by descending box SURFACE — the SAH's estimate of how likely a ray visits the node — taken
+    // from a priority queue that starts at the root, so a parent always precedes its children and the first N nodes are the N most
+    // visited ones (thai2: half of all inner-node visits go to the first 128 of 16 923 nodes, profiles/r03_notes.md).
+    // MI355RT_NODE_LAYOUT=bfs: plain breadth-first numbering (A/B; measured equal for the trace kernel without the LDS stage, as was
+    // a treelet layout that packs parent / child / grandchild into one 128-byte line — line misses are not what bounds it).
     std::vector<int32_t> inner_index(b.tmp.size(), -1);
-    std::vector<int32_t> bfs;
-    if (b.tmp[root].left >= 0) {
+    std::vector<int32_t> bfs;                       // layout order: tmp-node per slot
+    const char* layout_env = std::getenv("MI355RT_NODE_LAYOUT");
+    const bool by_area = !(layout_env && std::strcmp(layout_env, "bfs") == 0);
+    if (b.tmp[root].left >= 0 && !by_area) {
         std::queue<int32_t> q; q.push(root);
         while (!q.empty()) {
             int32_t n = q.front(); q.pop();
             inner_index[n] = (int32_t)bfs.size(); bfs.push_back(n);
             for (int32_t c : { b.tmp[n].left, b.tmp[n].right }) if (b.tmp[c].left >= 0) q.push(c);
+        }
+    } else if (b.tmp[root].left >= 0) {
+        auto surface = [&](int32_t n) { const Box& x = b.tmp[n].box; const float dx = x.mx[0] - x.mn[0], dy = x.mx[1] - x.mn[1], dz = x.mx[2] - x.mn[2]; return dx * dy + dy * dz + dz * dx; };
+        typedef std::pair<float, int32_t> Item;                           // (surface, -node): ties in creation order
+        std::priority_queue<Item> q;
+        q.push(Item(surface(root), -root));
+        while (!q.empty()) {
+            const int32_t n = -q.top().second; q.pop();
+            inner_index[n] = (int32_t)bfs.size(); bfs.push_back(n);
+            for (int32_t c : { b.tmp[n].left, b.tmp[n].right }) if (b.tmp[c].left >= 0) q.push(Item(surface(c), -c));
         }
     }
     auto emit_leaf = [&](const TmpNode& n) -> int32_t {

@@ -101,6 +101,7 @@ struct DCounters {            // one set per render call, zeroed at its start
     unsigned long long t_first_end, t_last_end, t_sum_end, t_start, n_waves;   // COUNT mode: wave end times (s_memrealtime ticks, 100 MHz)
     unsigned long long lanes_inner, lanes_leaf, lanes_done, lane_samples;   // COUNT mode: where the lanes are at every loop iteration (summed lane counts; samples = iterations)
     unsigned long long t_sum_cycles, t_sum_real;                                            // COUNT mode: summed s_memtime ticks (shader cycles) of the waves, against t_sum_end in s_memrealtime ticks
+    unsigned long long visits_below[6];                                          // COUNT mode: inner-node visits with node index < 64, 128, 256, 512, 1024, 2048 (what an LDS copy of the first N nodes would serve)
     unsigned long long refills, refill_passes, refill_rays;                    // COUNT mode: refill sections entered, passes through the assignment code, rays handed out
 };
 

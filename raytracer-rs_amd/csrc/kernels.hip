@@ -322,6 +322,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                                            DCounters* counters, int* stack, uint32_t single_chunk, uint32_t single_nrad, uint32_t single_nshadow)
 {
     uint32_t acc_nodes = 0, acc_tris = 0, acc_ie = 0, acc_le = 0;
+    uint32_t acc_below[6] = { 0, 0, 0, 0, 0, 0 };        // COUNT only: inner-node visits by node index
     uint32_t acc_li = 0, acc_ll = 0, acc_ld = 0, acc_it = 0, acc_rf = 0, acc_rp = 0, acc_rr = 0;       // COUNT only: lane census per iteration, refill statistics
     unsigned long long t_begin = 0, c_begin = 0;
     if (COUNT) { t_begin = __builtin_amdgcn_s_memrealtime(); c_begin = __builtin_amdgcn_s_memtime(); }
@@ -354,17 +355,17 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     // contains test of OCT:160-169 on the root cube.  Settled right here: no confirm launch for such scenes.
                     bool hit = rs.prim != kMiss;
                     if (hit) hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]),
-                                                 add3(rs.o, vscale(rs.d, rs.t)));
+                                                 add3(rs.o, vscale(rs.d, rs.tlimit)));
                     if (rs.occ < 0) {                                           // radiance ray
                         st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), hit ? rs.prim : kMiss);
-                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
-                    } else if (hit && rs.t > 0.01f && rs.t < 1.0f) {              // shadow ray (rec: its term), blocked (mod.rs:226-232)
+                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.tlimit, rs.u, rs.v, __uint_as_float(rs.prim)));
+                    } else if (hit && rs.tlimit > 0.01f && rs.tlimit < 1.0f) {      // shadow ray (rec: its term), blocked (mod.rs:226-232)
                         store_blocked(slot_L, rec);
                     }
                 } else
                 if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
                     st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), rs.prim);     // 4 B for every ray, the 16 B record only for hits
-                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
+                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.tlimit, rs.u, rs.v, __uint_as_float(rs.prim)));     // the closest hit's t is the search limit it left (leaf_pred)
                 } else if (rs.occ == 1) {                              // blocked, mod.rs:232
                     store_blocked(slot_L, rec);
                 }
@@ -439,19 +440,21 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         // section pops (or finishes) its own lanes, so a lane that leaves a node is busy again at once.
 #pragma unroll
         for (int u = 0; u < kInnerStepsPerIteration; ++u) {
-            if (__ballot(lane_at_inner(rs)) == 0ull) break;
-            inner_pred<COUNT>(sc, rs, stack, kBlock, acc_nodes);
+            const unsigned long long m_inner = __ballot(lane_at_inner(rs));
+            if (m_inner == 0ull) break;
+            inner_pred<COUNT>(sc, rs, stack, kBlock, acc_nodes, m_inner, COUNT ? acc_below : nullptr);
             if (COUNT) ++acc_ie;
         }
         const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
-            { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, acc_tris); if (COUNT) ++acc_le; }
+            { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, acc_tris, m_leaf); if (COUNT) ++acc_le; }
     }
     if (COUNT) {
-        for (int off = 32; off > 0; off >>= 1) { acc_nodes += __shfl_down((int)acc_nodes, off, 64); acc_tris += __shfl_down((int)acc_tris, off, 64); }
+        for (int off = 32; off > 0; off >>= 1) { acc_nodes += __shfl_down((int)acc_nodes, off, 64); acc_tris += __shfl_down((int)acc_tris, off, 64); for (int k = 0; k < 6; ++k) acc_below[k] += __shfl_down((int)acc_below[k], off, 64); }
         DCounters* cs = &counters[global_wave_id() % kShards];
         if (lane_id() == 0) {
             atomicAdd(&cs->nodes_visited, (unsigned long long)acc_nodes); atomicAdd(&cs->tris_tested, (unsigned long long)acc_tris);
+            for (int k = 0; k < 6; ++k) atomicAdd(&cs->visits_below[k], (unsigned long long)acc_below[k]);
             atomicAdd(&cs->inner_execs, (unsigned long long)acc_ie); atomicAdd(&cs->leaf_execs, (unsigned long long)acc_le);
             atomicAdd(&cs->lanes_inner, (unsigned long long)acc_li); atomicAdd(&cs->lanes_leaf, (unsigned long long)acc_ll); atomicAdd(&cs->lanes_done, (unsigned long long)acc_ld);
             atomicAdd(&cs->lane_samples, (unsigned long long)acc_it); atomicAdd(&cs->refills, (unsigned long long)acc_rf); atomicAdd(&cs->refill_passes, (unsigned long long)acc_rp);

@@ -648,11 +648,15 @@ bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
         c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
         c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs; c.primary_culled += s.primary_culled;
         c.t_sum_cycles += s.t_sum_cycles; c.t_sum_real += s.t_sum_real;
+        for (int k = 0; k < 6; ++k) c.visits_below[k] += s.visits_below[k];
     }
     counts = mi355rt_ray_counts{};
     counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
     counts.nodes_visited = c.nodes_visited; counts.tris_tested = c.tris_tested; counts.trace_launches = launches_;
     counts.inner_execs = c.inner_execs; counts.leaf_execs = c.leaf_execs; counts.primary_culled = c.primary_culled;
+    if (getenv("MI355RT_DEBUG_UTIL") && c.nodes_visited)
+        fprintf(stderr, "[mi355rt] inner-node visits with node index < 64 / 128 / 256 / 512 / 1024 / 2048: %.3f / %.3f / %.3f / %.3f / %.3f / %.3f of %llu\n", (double)c.visits_below[0] / c.nodes_visited, (double)c.visits_below[1] / c.nodes_visited,
+                (double)c.visits_below[2] / c.nodes_visited, (double)c.visits_below[3] / c.nodes_visited, (double)c.visits_below[4] / c.nodes_visited, (double)c.visits_below[5] / c.nodes_visited, c.nodes_visited);
     if (getenv("MI355RT_DEBUG_UTIL")) fprintf(stderr, "[mi355rt] inner execs %llu (lane util %.3f) leaf execs %llu (lane util %.3f)\n", c.inner_execs, c.inner_execs ? (double)c.nodes_visited / (64.0 * c.inner_execs) : 0.0, c.leaf_execs, c.leaf_execs ? (double)c.tris_tested / (64.0 * c.leaf_execs) : 0.0);
     if (timed_call) {
         float ms = 0.0f;
