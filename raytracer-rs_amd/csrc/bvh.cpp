@@ -184,16 +184,14 @@ void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, 
                            + (scene.mx[2] - scene.mn[2]) * (scene.mx[2] - scene.mn[2]));
     float pad = std::max(diag * 2e-5f, 1e-6f);
 
-    // Numbering of the inner nodes = their place in memory.  The first nodes are staged in LDS by the trace kernel (kernels.hip,
-    // node cache): the numbering is by descending box SURFACE — the SAH's estimate of how likely a ray visits the node — taken
-    // from a priority queue that starts at the root, so a parent always precedes its children and the first N nodes are the N most
-    // visited ones (thai2: half of all inner-node visits go to the first 128 of 16 923 nodes, profiles/r03_notes.md).
-    // MI355RT_NODE_LAYOUT=bfs: plain breadth-first numbering (A/B; measured equal for the trace kernel without the LDS stage, as was
-    // a treelet layout that packs parent / child / grandchild into one 128-byte line — line misses are not what bounds it).
+    // Numbering of the inner nodes = their place in memory: breadth-first (the top of the tree has the lowest indices).
+    // MI355RT_NODE_LAYOUT=area numbers them by descending box surface instead (a priority queue from the root: the first N nodes are
+    // the N a ray most probably visits).  Measured for the trace kernels (profiles/r03_notes.md): by surface +0.2 ms per frame, a treelet
+    // layout (parent / children / grandchild in one 128-byte line) +-0 — which lines a fetch touches is not what bounds them.
     std::vector<int32_t> inner_index(b.tmp.size(), -1);
     std::vector<int32_t> bfs;                       // layout order: tmp-node per slot
     const char* layout_env = std::getenv("MI355RT_NODE_LAYOUT");
-    const bool by_area = !(layout_env && std::strcmp(layout_env, "bfs") == 0);
+    const bool by_area = layout_env && std::strcmp(layout_env, "area") == 0;
     if (b.tmp[root].left >= 0 && !by_area) {
         std::queue<int32_t> q; q.push(root);
         while (!q.empty()) {

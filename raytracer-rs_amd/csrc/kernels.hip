@@ -355,17 +355,17 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     // contains test of OCT:160-169 on the root cube.  Settled right here: no confirm launch for such scenes.
                     bool hit = rs.prim != kMiss;
                     if (hit) hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]),
-                                                 add3(rs.o, vscale(rs.d, rs.tlimit)));
+                                                 add3(rs.o, vscale(rs.d, rs.t)));
                     if (rs.occ < 0) {                                           // radiance ray
                         st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), hit ? rs.prim : kMiss);
-                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.tlimit, rs.u, rs.v, __uint_as_float(rs.prim)));
-                    } else if (hit && rs.tlimit > 0.01f && rs.tlimit < 1.0f) {      // shadow ray (rec: its term), blocked (mod.rs:226-232)
+                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
+                    } else if (hit && rs.t > 0.01f && rs.t < 1.0f) {              // shadow ray (rec: its term), blocked (mod.rs:226-232)
                         store_blocked(slot_L, rec);
                     }
                 } else
                 if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
                     st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), rs.prim);     // 4 B for every ray, the 16 B record only for hits
-                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.tlimit, rs.u, rs.v, __uint_as_float(rs.prim)));     // the closest hit's t is the search limit it left (leaf_pred)
+                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
                 } else if (rs.occ == 1) {                              // blocked, mod.rs:232
                     store_blocked(slot_L, rec);
                 }
@@ -440,14 +440,13 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         // section pops (or finishes) its own lanes, so a lane that leaves a node is busy again at once.
 #pragma unroll
         for (int u = 0; u < kInnerStepsPerIteration; ++u) {
-            const unsigned long long m_inner = __ballot(lane_at_inner(rs));
-            if (m_inner == 0ull) break;
-            inner_pred<COUNT>(sc, rs, stack, kBlock, acc_nodes, m_inner, COUNT ? acc_below : nullptr);
+            if (__ballot(lane_at_inner(rs)) == 0ull) break;
+            inner_pred<COUNT>(sc, rs, stack, kBlock, acc_nodes, COUNT ? acc_below : nullptr);
             if (COUNT) ++acc_ie;
         }
         const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
-            { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, acc_tris, m_leaf); if (COUNT) ++acc_le; }
+            { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, acc_tris); if (COUNT) ++acc_le; }
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { acc_nodes += __shfl_down((int)acc_nodes, off, 64); acc_tris += __shfl_down((int)acc_tris, off, 64); for (int k = 0; k < 6; ++k) acc_below[k] += __shfl_down((int)acc_below[k], off, 64); }

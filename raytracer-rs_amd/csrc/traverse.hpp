@@ -182,77 +182,51 @@ __device__ __forceinline__ bool lane_at_leaf(const RayState& s) { return (uint32
 // sentinel when nothing is deferred — so "stack empty => ray finished" needs no compare and no select; lanes that do not
 // pop read the same (valid) row and drop the value.  A push writes row sp + 1; lanes that do not push write there too:
 // above the top is free space (one spare row is allocated), so that needs no select either.
-// v + 1 / v - 1 in the lanes of mask m, as ONE vector instruction: the mask goes in as the carry / borrow
-// (the compiler's form for a mask that lives in scalar registers is v_cndmask 0/1 + v_add)
-__device__ __forceinline__ int add_lanes(int v, unsigned long long m)
-{
-    int r; unsigned long long carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(v), "s"(m));
-    return r;
-}
-__device__ __forceinline__ int sub_lanes(int v, unsigned long long m)
-{
-    int r; unsigned long long borrow_out;
-    asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(borrow_out) : "v"(v), "s"(m));
-    return r;
-}
-
-__device__ __forceinline__ int pop_or_finish(RayState& s, unsigned long long m_want, const int* stack, int stride)
+__device__ __forceinline__ int pop_or_finish(RayState& s, bool want, const int* stack, int stride)
 {
     const int popped = stack[s.sp * stride];
-    s.sp = max(sub_lanes(s.sp, m_want), 0);
+    s.sp = max(s.sp - (want ? 1 : 0), 0);
     return popped;
 }
 
 template <bool COUNT>
-__device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* stack, int stride, uint32_t& n_nodes, const unsigned long long m_pred, uint32_t* below = nullptr)
+__device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* stack, int stride, uint32_t& n_nodes, uint32_t* below = nullptr)
 {
-    // m_pred = ballot(s.node >= 0): the lanes at an inner node, from the caller (it branches on the same mask).
-    // The lane predicates are LANE MASKS (ballot -> 64-bit scalar -> inverse ballot): their and / or / not run on the scalar
-    // unit, which has slots to spare, instead of as 0/1 integers on the vector unit (what the compiler makes of
-    // `pred & h0 & h1` on bools: three v_cndmask 0/1, a v_bitop3, a v_or, a v_cmp).
+    const bool pred = s.node >= 0;
     if (COUNT) {
-        n_nodes += s.node >= 0 ? 1u : 0u;
-        if (below) for (int k = 0; k < 6; ++k) below[k] += (s.node >= 0 && s.node < (64 << k)) ? 1u : 0u;      // what an LDS copy of the first 64 .. 2048 nodes would serve
+        n_nodes += pred ? 1u : 0u;
+        if (below) for (int k = 0; k < 6; ++k) below[k] += (pred && s.node < (64 << k)) ? 1u : 0u;      // what an LDS copy of the first 64 .. 2048 nodes would serve (profiles/r03_notes.md)
     }
-#ifdef MI355RT_EXP_SPREADIDLE    // timing experiment (same results): idle lanes read 64 different lines instead of node 0 — is a load priced per instruction or per line?
-    const uint32_t off = s.node >= 0 ? (uint32_t)s.node << 5 : ((uint32_t)lane_id() << 12) + 4096u * 5u;
-#else
-    const uint32_t off = (uint32_t)max(s.node, 0) << 5;              // 32-byte nodes, unsigned 32-bit byte offset
-#endif
+    const uint32_t off = pred ? (uint32_t)s.node << 5 : 0u;           // 32-byte nodes, unsigned 32-bit byte offset
     const char* __restrict__ base = (const char*)sc.nodes;
-    // (lanes that are not at an inner node read node 0: one address for all of them.  Running the loads under the lanes' own exec
-    // mask instead was measured 1 % slower, profiles/r03_notes.md.)
     const uint4 q0 = *(const uint4*)(base + off), q1 = *(const uint4*)(base + off + 16u);
-#ifdef MI355RT_EXP_EXTRALOAD     // timing experiment (same results): one more divergent 16-byte load per inner step, its value unused — is the step bound by the vector memory pipe?
+#ifdef MI355RT_EXP_EXTRALOAD     // timing experiment (same results): one more divergent 16-byte load per inner step, its value unused — is the step bound by the vector memory pipe?  (yes: +22 % trace time, profiles/r03_notes.md)
     { const uint4 qx = *(const uint4*)((const char*)sc.tris + off); asm volatile("" : : "v"(qx.x), "v"(qx.y), "v"(qx.z), "v"(qx.w)); }
 #endif
     float tn0, tf0, tn1, tf1;
     slab_child(q0, s, tn0, tf0);
     slab_child(q1, s, tn1, tf1);
-    const unsigned long long m_h0 = __ballot(tn0 <= tf0), m_h1 = __ballot(tn1 <= tf1), m_sw = __ballot(tn1 < tn0);   // sw: child 1 is nearer
-    const bool take1 = __builtin_amdgcn_inverse_ballot_w64(m_h1 & (~m_h0 | m_sw));
-    const unsigned long long m_none = m_pred & ~(m_h0 | m_h1);
-    const bool none = __builtin_amdgcn_inverse_ballot_w64(m_none);
+    // bitwise & | on bools throughout: && || would compile to short-circuit branches
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
     const int c0i = (int)q0.w, c1i = (int)q1.w;
+    const bool sw = tn1 < tn0;                       // child 1 is nearer
+    const bool take1 = h1 & (!h0 | sw);
     const int near_c = take1 ? c1i : c0i, far_c = take1 ? c0i : c1i;
+    const bool push = pred & h0 & h1;
+    const bool none = pred & !(h0 | h1);
     stack[(s.sp + 1) * stride] = far_c;              // row above the top: kept only if sp is incremented
-    s.sp = add_lanes(s.sp, m_pred & m_h0 & m_h1);    // push
-    const int next = pop_or_finish(s, m_none, stack, stride);
-    s.node = __builtin_amdgcn_inverse_ballot_w64(m_pred) ? (none ? next : near_c) : s.node;
+    s.sp += push ? 1 : 0;
+    const int next = pop_or_finish(s, none, stack, stride);
+    s.node = pred ? (none ? next : near_c) : s.node;
 }
 
 // CLOSEST_ONLY (reference-default semantics): every ray wants its closest hit with t <= tlimit — radiance
 // rays start with tlimit = inf, shadow rays with the largest float below 1 (mod.rs:226-229 needs the CLOSEST hit of the
 // reference's intersector, which the octree confirm step derives from the true closest hit).  No occlusion state.
 template <bool COUNT, bool CLOSEST_ONLY>
-__device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const int* stack, int stride, uint32_t& n_tris, const unsigned long long m_pred)
+__device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const int* stack, int stride, uint32_t& n_tris)
 {
-    // m_pred = ballot(lane_at_leaf(s)), from the caller (it branches on the same mask).
-    // s.t is NOT used on this path: the closest hit's distance is s.tlimit (a hit sets both to the same value, and before the first
-    // hit `prim < 0xFFFFFFFF` makes the tie rule below a plain `t <= tlimit`); the finish code reads s.tlimit.  One register and
-    // three instructions less than carrying both.
-    const bool pred = __builtin_amdgcn_inverse_ballot_w64(m_pred);
+    const bool pred = lane_at_leaf(s);
     const uint32_t code = ~(uint32_t)s.node;
     if (COUNT) n_tris += pred ? 1u : 0u;
     const uint32_t off = pred ? (code >> 3) * 48u : 0u;              // 48-byte triangles, unsigned 32-bit byte offset
@@ -270,24 +244,22 @@ __device__ __forceinline__ void leaf_pred(const DScene& sc, RayState& s, const i
     const float t = dot3(v0v2, qvec) * inv_det;
     const bool ok = pred & !(fabsf(det) < 1.1920929e-7f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(t < 0.0f);
     const uint32_t prim = __float_as_uint(t0.w);
-    const unsigned long long m_last = m_pred & __ballot((code & 7u) == 0u);
-    const bool last = __builtin_amdgcn_inverse_ballot_w64(m_last);
+    const bool last = (code & 7u) == 0u;
     if (CLOSEST_ONLY) {
-        // lowest t, ties to the lowest triangle index (the first in the reference's list order); t <= tlimit before the first hit
-        const bool better = ok & ((t < s.tlimit) | ((t == s.tlimit) & (prim < s.prim)));
-        s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
+        const bool better = ok & (t <= s.tlimit) & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
+        s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
         s.tlimit = better ? t : s.tlimit;
-        const int next = pop_or_finish(s, m_last, stack, stride);
+        const int next = pop_or_finish(s, pred & last, stack, stride);
         s.node = pred ? (last ? next : s.node - 7) : s.node;
     } else {
         const bool is_shadow = s.occ >= 0;
-        const bool better = ok & !is_shadow & ((t < s.tlimit) | ((t == s.tlimit) & (prim < s.prim)));
-        s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
+        const bool better = ok & !is_shadow & ((s.prim == 0xFFFFFFFFu) | (t < s.t) | ((t == s.t) & (prim < s.prim)));
+        s.t = better ? t : s.t; s.u = better ? u : s.u; s.v = better ? v : s.v; s.prim = better ? prim : s.prim;
         const bool sh = ok & is_shadow & (t <= s.tlimit);
         const bool sh_far = sh & (t > 0.01f), sh_near = sh & !(t > 0.01f);
         s.tlimit = better ? t : (sh_far ? 0.01f : s.tlimit);
         s.occ = sh_near ? 2 : (sh_far ? 1 : s.occ);
-        const int next = pop_or_finish(s, m_last & ~__ballot(sh_near), stack, stride);
+        const int next = pop_or_finish(s, pred & last & !sh_near, stack, stride);
         s.node = pred ? (sh_near ? kNodeFin : (last ? next : s.node - 7)) : s.node;
     }
 }
