@@ -27,14 +27,18 @@ dealt to the N ranks) and `c5` (BASELINE config 5, the fixed 3840x2160 x 256 fra
 ms_per_step, gather_ms_rank0, gather_path ("none" | "library_rccl" | "torch_all_gather"), rccl_ranks (what ncclCommCount
 returned) and gather_error (null unless the library's RCCL path was refused and torch's all_gather stood in).
 Extra objects of the line:
-  roofline      dominant kernel = trace_kernel (closest-hit traversal), secondary launches.  It is bound by vector-ALU
-                ISSUE, not by memory (the 1.5 MB scene is cache-resident): `bound` = "valu";
-                achieved = SQ_INSTS_VALU per secondary trace launch (a rocprofv3 --pmc child pass of THIS run)
-                           / the average duration of a secondary trace launch (HIP events around those launches, this process);
-                peak     = 1024 SIMDs x 2400 MHz / 4 cycles per wave64 VALU instruction; frac = achieved / peak.
-                Next to it: the clock the trace waves were observed to run at (s_memtime / s_memrealtime inside the
-                instrumented launch) and frac against THAT clock, the SQ busy-cycle issue fraction (a separate field), the
-                useful-lane fractions of the inner-node and triangle sections (live, MI355RT_FLAG_COUNT_STEPS), the SURVEY.md 8d
+  roofline      dominant kernel = trace_kernel (closest-hit traversal), secondary launches.  It is bound by the CU's VECTOR MEMORY
+                PIPE (texture addresser / L1 / data return: TA busy 0.91, TD busy 0.95 of its cycles), not by HBM (the 1.5 MB scene
+                is cache-resident), not by VALU issue (12 % fewer instructions in the hot block change nothing, one more divergent
+                load per step costs 22 %: profiles/r03_notes.md): `bound` = "vmem_gather", unit = G cache-line accesses/s;
+                achieved = TCP_TOTAL_CACHE_ACCESSES per secondary ray (a rocprofv3 --pmc child pass of THIS run) x secondary rays
+                           per launch / the average duration of a secondary trace launch (HIP events, this process);
+                peak     = the rate at which this device's pipe serves the same kind of fetch and nothing else, measured live
+                           (mi355rt_debug_gather_rate: 8 waves per SIMD walk random 32-byte nodes of an L2-resident table with the
+                           inner step's two 16-byte loads); frac = achieved / peak.
+                Next to it: TA / TD busy fractions, the VALU issue rate against the REAL peak (one wave64 instruction per 2 cycles
+                per SIMD, MI355X_MICROARCH.md; round 2 divided by 4 cycles), the clock the trace waves were observed to run at,
+                the useful-lane fractions of the inner-node and triangle sections (live, MI355RT_FLAG_COUNT_STEPS), the SURVEY.md 8d
                 LOGICAL byte rate (labelled logical: it exceeds the HBM peak because node and triangle bytes are cache
                 hits) and the measured HBM traffic per launch (`traffic`, PMC FETCH_SIZE x 2 + WRITE_SIZE as
                 MI355X_MICROARCH.md prescribes for gfx950).  PMC fields are null when the child passes are skipped
@@ -130,9 +134,11 @@ def self_launch(args, argv):
 # ------------------------------------------------------------------------------------------------------------------
 # rocprofv3 --pmc child passes (N = 1, rank 0, BEFORE this process touches the GPU): the same frame under counter
 # collection, one pass per counter group (TCC slots: FETCH_SIZE and WRITE_SIZE cannot share a pass).
-PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"],
+PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "TA_TA_BUSY_sum", "TD_TD_BUSY_sum"],
+              ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "SQ_INSTS_VMEM_RD", "TCP_GATE_EN1_sum"],
               ["FETCH_SIZE"], ["WRITE_SIZE"]]
 PMC_CHILD_FRAMES = 2
+GATHER_TABLE_NODES, GATHER_STEPS = 48000, 2000     # mi355rt_debug_gather_rate: a 1.5 MB table (L2-resident like the scene), 2000 dependent fetches per lane
 
 
 def pmc_child(args):
@@ -154,14 +160,15 @@ def pmc_child(args):
     for _ in range(PMC_CHILD_FRAMES):
         rt.film.clear()
         rt.render(args.spp or SPP)
+    rt.debug_gather_rate(GATHER_TABLE_NODES, GATHER_STEPS)         # the roofline's peak kernel under the same counters (3 launches)
 
 
-def run_pmc_passes(args, kernel_substr):
-    """-> dict counter -> (sum over dispatches, dispatches) for kernels whose name contains kernel_substr; {} on failure."""
+def run_pmc_passes(args, kernel_substrs):
+    """-> {substr: {counter: (sum over dispatches, dispatches)}} for the kernels whose name contains each substr; ({}, note) on failure."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {}, "rocprofv3 not found"
-    out = {}
+    out = {k: {} for k in kernel_substrs}
     base = tempfile.mkdtemp(prefix="mi355rt_pmc_", dir="/tmp")
     env = dict(os.environ); env["TMPDIR"] = "/tmp"
     child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
@@ -182,14 +189,13 @@ def run_pmc_passes(args, kernel_substr):
                 break
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if kernel_substr not in row["Kernel_Name"]:
-                        continue
-                    name = row["Counter_Name"]
-                    acc = out.setdefault(name, [0.0, set()])
-                    acc[0] += float(row["Counter_Value"]); acc[1].add(row["Dispatch_Id"])
+                    for sub in kernel_substrs:
+                        if sub in row["Kernel_Name"]:
+                            acc = out[sub].setdefault(row["Counter_Name"], [0.0, set()])
+                            acc[0] += float(row["Counter_Value"]); acc[1].add(row["Dispatch_Id"])
     finally:
         shutil.rmtree(base, ignore_errors=True)
-    return {k: (v[0], len(v[1])) for k, v in out.items()}, note
+    return {sub: {k: (v[0], len(v[1])) for k, v in d.items()} for sub, d in out.items()}, note
 
 
 def cpu_model():
@@ -280,11 +286,11 @@ class FrameSetup:
             self.ctx.dist.barrier()
         torch.cuda.synchronize()
 
-    def step(self, time_gather=False):
+    def step(self, time_gather=False, wait=True):
         import torch
         rt = self.rt
         rt.film.clear()
-        counts = rt.render(self.spp)                                    # synchronous: returns when the frame is traced
+        counts = rt.render(self.spp, wait=wait)                         # wait: returns when the frame is traced; else queued only (mi355rt_render_async)
         t0 = time.perf_counter()
         if self.native is not None:
             self.native.gather()                                        # tonemap + RCCL inside the library, on its own stream
@@ -298,21 +304,28 @@ class FrameSetup:
 
     def timed(self, steps, warmup):
         """`warmup` untimed frames, then EXACTLY `steps` frames between two (barrier + device synchronisation)s;
-        -> elapsed seconds (max over ranks), ray sums over ranks, rank-0 per-step times"""
+        -> elapsed seconds (max over ranks), ray sums over ranks, rank-0 per-step host times of the (synchronous) warm-up frames.
+        The timed frames are QUEUED (mi355rt_render_async + the gather on its stream): the device runs them back to back and the
+        closing synchronisation waits for all of them.  Every frame is the same frame (film cleared, same seed): its ray counters
+        are read once, after the loop, checked against a synchronous frame's, and counted `steps` times."""
         import torch
-        for _ in range(warmup):
-            self.step()
+        ref = None
+        step_ms = []
+        for _ in range(max(warmup, 1)):
+            ts = time.perf_counter()
+            ref = self.step()
+            step_ms.append((time.perf_counter() - ts) * 1e3)
         self.sync()
         t0 = time.perf_counter()
-        tot = [0.0, 0.0, 0.0, 0.0]
-        step_ms = []
         for _ in range(steps):
-            ts = time.perf_counter()
-            c = self.step()                                             # the frame is complete when render() returns; the gather is queued
-            step_ms.append((time.perf_counter() - ts) * 1e3)
-            tot[0] += c.primary; tot[1] += c.bounce; tot[2] += c.shadow; tot[3] += c.primary_culled
+            self.step(wait=False)
         self.sync()
         elapsed = time.perf_counter() - t0
+        c = self.rt.last_counts()
+        same = (c.primary, c.bounce, c.shadow, c.primary_culled) == (ref.primary, ref.bounce, ref.shadow, ref.primary_culled)
+        if not same:
+            raise SystemExit("bench: a queued frame traced other rays than the synchronous one: %s vs %s" % (c.as_dict(), ref.as_dict()))
+        tot = [float(steps * c.primary), float(steps * c.bounce), float(steps * c.shadow), float(steps * c.primary_culled)]
         for _ in range(2):                                              # the gather timed on its own (render excluded)
             self.step(time_gather=True)
         self.sync()
@@ -386,9 +399,11 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     # counter passes first: this process has not initialised the GPU yet, so the children have the device to themselves
-    pmc, pmc_note = ({}, "skipped (--no-pmc)") if args.no_pmc else ({}, "skipped (N > 1)")
+    pmc, pmc_gather, pmc_note = {}, {}, ("skipped (--no-pmc)" if args.no_pmc else "skipped (N > 1)")
     if not args.no_pmc and world == 1:
-        pmc, pmc_note = run_pmc_passes(args, "fused_pass_kernel" if args.mode == "dropin" else "trace_kernel<false, false")
+        main_kernel = "fused_pass_kernel" if args.mode == "dropin" else "trace_kernel<false, false"
+        both, pmc_note = run_pmc_passes(args, [main_kernel, "gather_rate_kernel"])
+        pmc, pmc_gather = both.get(main_kernel, {}), both.get("gather_rate_kernel", {})
 
     import torch                                                       # before the library: see raytracer-rs_amd/__init__.py lib()
     import __graft_entry__ as ge
@@ -463,6 +478,12 @@ def main(argv=None):
     fs.sync()
     serial_ms_per_step = (time.perf_counter() - t1) / ksteps * 1e3
     rt.set_flags(base_flags)
+    gather = None
+    if rank == 0:
+        try:
+            gather = rt.debug_gather_rate(48000, 2000)              # 1.5 MB table: L2-resident like the scene
+        except Exception as e:                                      # noqa: BLE001 — the line then carries a null peak
+            gather = None
     main_group = fs.summary(workload_text(args, width, height, spp, base_spp, world, args.scaling, c5=args.config == "c5"), args.scaling, args.steps, args.warmup, elapsed, vals)
     acc = rt.accel_stats()
     build_info = rt.bvh_build_info()
@@ -499,18 +520,23 @@ def main(argv=None):
         sec_launch_s = k["sec_ms"] * 1e-3 / max(k["sec_launches"], 1)
         prim_launch_s = (k["trace_ms"] - k["sec_ms"]) * 1e-3 / max(prim_launches, 1)
         logical_gbs = k["rays"] * bytes_per_ray / (k["trace_ms"] * 1e-3) / 1e9 if k["trace_ms"] > 0 else 0.0
-        peak_winst = NUM_SIMDS * NOMINAL_MHZ * 1e6 / 4.0 / 1e9                     # G wave64 VALU instructions per second
-        roof = {"bound": "valu", "kernel": "trace_kernel<secondary>", "unit": "G wave-instr/s", "peak": round(peak_winst, 1),
-                "peak_is": "%d SIMDs x %.0f MHz (nominal maximum clock) / 4 cycles per wave64 VALU instruction" % (NUM_SIMDS, NOMINAL_MHZ),
+        peak_winst = NUM_SIMDS * NOMINAL_MHZ * 1e6 / 2.0 / 1e9                     # G wave64 VALU instructions per second (2-cycle throughput)
+        sec_rays_launch = k["sec_rays"] / max(k["sec_launches"], 1)
+        roof = {"bound": "vmem_gather", "kernel": "trace_kernel<secondary>", "unit": "G cache-line accesses/s",
+                "bound_is": "the CU's vector memory pipe (TA / TCP / TD) serving divergent 16-byte fetches of cache-resident nodes and triangles: the counters, the "
+                            "A/B experiments and the microbenchmark are in profiles/r03_notes.md",
+                "peak": None,
+                "peak_is": "measured on this device in this run (mi355rt_debug_gather_rate): every lane of 8 waves per SIMD walks a dependent chain of random 32-byte "
+                           "nodes of a 1.5 MB table with two 16-byte loads per node, grid = the whole chip; its TCP_TOTAL_CACHE_ACCESSES per launch (the same counter, the same "
+                           "rocprofv3 pass as `achieved`; the counter reads 2 per lane and 16-byte load) / its duration in this process" + (" (%.3f ms)" % gather["ms"] if gather else ""),
                 "achieved": None, "frac": None,
-                "achieved_is": "SQ_INSTS_VALU per secondary trace launch (rocprofv3 --pmc child of this run) / average duration of a secondary trace launch (HIP events, this process)",
+                "achieved_is": "TCP_TOTAL_CACHE_ACCESSES per secondary ray (rocprofv3 --pmc child of this run) x secondary rays per launch / average duration of a secondary trace launch (HIP events, this process)",
                 "clock_mhz_nominal": NOMINAL_MHZ, "clock_mhz_observed": round(observed_mhz, 1) if observed_mhz else None,
                 "clock_observed_is": "sum of delta s_memtime / sum of delta s_memrealtime x 100 MHz over all waves of the instrumented frame's trace launches",
-                "frac_of_observed_clock_peak": None,
                 "useful_lane_frac_inner": round(lane_inner, 3) if lane_inner else None, "useful_lane_frac_leaf": round(lane_leaf, 3) if lane_leaf else None,
                 "secondary_launches": int(k["sec_launches"]), "avg_secondary_launch_ms": round(sec_launch_s * 1e3, 4),
                 "primary_launches": int(prim_launches), "avg_primary_launch_ms": round(prim_launch_s * 1e3, 4),
-                "secondary_rays_per_launch": round(k["sec_rays"] / max(k["sec_launches"], 1), 1),
+                "secondary_rays_per_launch": round(sec_rays_launch, 1),
                 "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2), "node_bytes": node_bytes,
                 "logical": {"what": "SURVEY.md 8d algorithmic bytes: node_bytes x nodes + 48 x triangles + 96 per ray; node and triangle bytes are CACHE hits "
                                     "(1.5 MB scene), so this is not HBM traffic and may exceed the HBM peak",
@@ -519,46 +545,64 @@ def main(argv=None):
                 "traffic": None, "hbm": None,
                 "timing": "HIP events around every trace launch in a second loop of %d frames with 1 slice (%.2f ms/frame); the headline frames run %d "
                           "concurrent slices whose kernels overlap" % (ksteps, serial_ms_per_step, slices),
-                "pmc": {"source": "rocprofv3 --pmc child passes of this same run (bench.py --pmc-child: %d frames, 1 slice), secondary trace launches" % PMC_CHILD_FRAMES, "note": pmc_note}}
-        if "SQ_INSTS_VALU" in pmc:
-            v, n = pmc["SQ_INSTS_VALU"]
-            inst_per_launch = v / max(n, 1)
-            sec_rays_launch = k["sec_rays"] / max(k["sec_launches"], 1)
-            roof["pmc"]["dispatches"] = n
-            roof["pmc"]["valu_winst_per_launch"] = round(inst_per_launch, 1)
-            roof["pmc"]["valu_winst_per_secondary_ray"] = round(inst_per_launch / max(sec_rays_launch, 1), 2)
-            roof["pmc"]["salu_inst_per_secondary_ray"] = round(pmc.get("SQ_INSTS_SALU", (0, 0))[0] / max(n, 1) / max(sec_rays_launch, 1), 2)
+                "pmc": {"source": "rocprofv3 --pmc child passes of this same run (bench.py --pmc-child: %d frames, 1 slice), secondary trace launches; counters are used PER RAY "
+                                  "(same frame, same seed, same passes as the timed process)" % PMC_CHILD_FRAMES, "note": pmc_note}}
+        child_sec_rays = (bounce + shadow) / max(args.steps * world, 1) * PMC_CHILD_FRAMES       # secondary rays the child's frames trace (same frame, same seed)
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc and child_sec_rays > 0:
+            acc_per_ray = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"][0] / child_sec_rays
+            roof["pmc"]["cache_line_accesses_per_secondary_ray"] = round(acc_per_ray, 2)
+            if "SQ_INSTS_VMEM_RD" in pmc:
+                roof["pmc"]["vmem_read_winst_per_secondary_ray"] = round(pmc["SQ_INSTS_VMEM_RD"][0] / child_sec_rays, 3)
+                roof["pmc"]["cache_line_accesses_per_vmem_read"] = round(pmc["TCP_TOTAL_CACHE_ACCESSES_sum"][0] / max(pmc["SQ_INSTS_VMEM_RD"][0], 1), 1)
+            if "TCP_TCC_READ_REQ_sum" in pmc:
+                roof["pmc"]["l1_miss_per_access"] = round(pmc["TCP_TCC_READ_REQ_sum"][0] / max(pmc["TCP_TOTAL_CACHE_ACCESSES_sum"][0], 1), 3)
+            if gather and "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc_gather:
+                ga, gn = pmc_gather["TCP_TOTAL_CACHE_ACCESSES_sum"]
+                roof["peak"] = round(ga / max(gn, 1) / (gather["ms"] * 1e-3) / 1e9, 1)
+                roof["pmc"]["gather_kernel"] = {"cache_line_accesses_per_launch": ga / max(gn, 1), "launches": gn,
+                                                "accesses_per_lane_and_load": round(ga / max(gn, 1) / (gather["line_accesses_per_s"] * gather["ms"] * 1e-3), 3)}
             if sec_launch_s > 0:
-                achieved = inst_per_launch / sec_launch_s / 1e9
+                achieved = acc_per_ray * sec_rays_launch / sec_launch_s / 1e9
                 roof["achieved"] = round(achieved, 1)
-                roof["frac"] = round(achieved / peak_winst, 4)
-                if observed_mhz:
-                    roof["frac_of_observed_clock_peak"] = round(achieved / (NUM_SIMDS * observed_mhz * 1e6 / 4.0 / 1e9), 4)
+                if roof["peak"]:
+                    roof["frac"] = round(achieved / roof["peak"], 4)
+        if "SQ_INSTS_VALU" in pmc and child_sec_rays > 0:
+            v, n = pmc["SQ_INSTS_VALU"]
+            roof["pmc"]["dispatches"] = n
+            roof["pmc"]["valu_winst_per_secondary_ray"] = round(v / child_sec_rays, 2)
+            roof["pmc"]["salu_inst_per_secondary_ray"] = round(pmc.get("SQ_INSTS_SALU", (0, 0))[0] / child_sec_rays, 2)
+            if sec_launch_s > 0:
+                valu_rate = v / child_sec_rays * sec_rays_launch / sec_launch_s / 1e9
+                roof["valu"] = {"achieved_g_winst_per_s": round(valu_rate, 1), "peak_g_winst_per_s": round(peak_winst, 1), "frac": round(valu_rate / peak_winst, 4),
+                                "peak_is": "%d SIMDs x %.0f MHz / 2 cycles per wave64 VALU instruction (throughput with several waves per SIMD, MI355X_MICROARCH.md; "
+                                           "4 cycles is ONE wave's issue cost — the divisor round 2 used, which put the primary trace kernel at 1.05)" % (NUM_SIMDS, NOMINAL_MHZ)}
             if "SQ_BUSY_CYCLES" in pmc and pmc["SQ_BUSY_CYCLES"][0] > 0:
                 busy = pmc["SQ_BUSY_CYCLES"][0] / NUM_SE                          # cycles during which the shader engines had waves
-                roof["pmc"]["valu_issue_frac_of_busy_cycles"] = round(v * 4.0 / NUM_SIMDS / busy, 4)
-                roof["pmc"]["busy_cycles_is"] = "SQ_INSTS_VALU x 4 / %d SIMDs over SQ_BUSY_CYCLES / %d shader engines; an SE counts busy while ANY of its waves lives, " \
-                                                "so the ratio can pass 1 when SEs drain at different times — kept as a cross-check, not as frac" % (NUM_SIMDS, NUM_SE)
-            if "SQ_THREAD_CYCLES_VALU" in pmc and v > 0:
-                roof["pmc"]["exec_lanes_per_valu_inst"] = round(pmc["SQ_THREAD_CYCLES_VALU"][0] / v, 1)
+                roof["pmc"]["valu_issue_per_simd_cycle"] = round(v / NUM_SIMDS / busy, 4)
+                if "TA_TA_BUSY_sum" in pmc:
+                    roof["pmc"]["ta_busy_frac"] = round(pmc["TA_TA_BUSY_sum"][0] / 256.0 / busy, 3)
+                if "TD_TD_BUSY_sum" in pmc:
+                    roof["pmc"]["td_busy_frac"] = round(pmc["TD_TD_BUSY_sum"][0] / 256.0 / busy, 3)
+                roof["pmc"]["busy_is"] = "per CU and busy cycle: TA_TA_BUSY_sum (TD_TD_BUSY_sum) / 256 CUs over SQ_BUSY_CYCLES / %d shader engines, same pass" % NUM_SE
             if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
                 roof["pmc"]["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"][0] / pmc["SQ_WAVE_CYCLES"][0], 3)
-            if lane_inner and lane_leaf and roof["frac"]:
-                roof["useful_issue_frac_upper"] = round(roof["frac"] * max(lane_inner, lane_leaf), 4)
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and child_sec_rays > 0:
             f, nf = pmc["FETCH_SIZE"]; w, nw = pmc["WRITE_SIZE"]
-            per_launch = (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0                     # KB -> B; FETCH_SIZE doubled (gfx950 wide reads)
+            per_ray = (2.0 * f + w) * 1024.0 / child_sec_rays                                # KB -> B; FETCH_SIZE doubled (gfx950 wide reads)
+            per_launch = per_ray * sec_rays_launch
             roof["traffic"] = round(per_launch, 1)
-            roof["hbm"] = {"bytes_per_launch": round(per_launch, 1), "gbs": round(per_launch / sec_launch_s / 1e9, 1) if sec_launch_s > 0 else None,
+            roof["hbm"] = {"bytes_per_launch": round(per_launch, 1), "bytes_per_secondary_ray": round(per_ray, 2), "gbs": round(per_launch / sec_launch_s / 1e9, 1) if sec_launch_s > 0 else None,
                            "frac_of_hbm_peak": round(per_launch / sec_launch_s / 1e9 / HBM_PEAK_GBS, 4) if sec_launch_s > 0 else None,
-                           "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / dispatches"}
+                           "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / secondary rays of the child's frames x secondary rays per launch"}
         out = {
             "metric": "Mrays/s (whole node) + ms/frame, 1920x1080x64spp thai2.dae",
             "value": main_group["value"],
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_group["ms_per_step"],
-            "ms_per_step_median_rank0": round(sorted(step_ms)[len(step_ms) // 2], 3), "ms_per_step_min_rank0": round(min(step_ms), 3),
+            "ms_per_synchronous_step_rank0": round(min(step_ms), 3),
+            "pipelining": "the %d timed frames are queued (mi355rt_render_async) between the two synchronisations and run back to back on the device; "
+                          "ms_per_synchronous_step_rank0 is the best warm-up frame, rendered with a host wait per frame" % args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": main_group["workload"], "scene": args.scene, "width": width, "height": height, "spp_per_gpu": spp if args.scaling == "strong" else base_spp,

@@ -167,7 +167,11 @@ uint32_t mi355rt_trace_frame_additive(mi355rt_handle* h);
 /* Whole frame (owned stripes) x spp samples per pixel — the benchmark entry; no reference
  * counterpart (the reference has no spp concept).  counts may be NULL. */
 int mi355rt_render(mi355rt_handle* h, uint32_t spp, mi355rt_ray_counts* counts);
-/* counters of the last trace_frame_additive / render call (waits for an asynchronous 50-row frame to finish) */
+/* The same frame, QUEUED only: returns as soon as the launches are on the handle's stream(s), like mi355rt_trace_frame_additive does;
+ * mi355rt_last_counts / mi355rt_synchronize / any read-out waits for it.  Consecutive frames then run back to back on the device
+ * (every later call on the handle is ordered behind it).  A device group of several devices still waits. */
+int mi355rt_render_async(mi355rt_handle* h, uint32_t spp);
+/* counters of the last trace_frame_additive / render call (waits for an asynchronous call to finish) */
 int mi355rt_last_counts(mi355rt_handle* h, mi355rt_ray_counts* counts);
 
 /* RayTracer::get_tonemapped_pixels, mod.rs:120-128: width*height u32 0xAARRGGBB (A = 255). */
@@ -254,6 +258,11 @@ int mi355rt_bvh_build_info(const mi355rt_handle* h, uint32_t out[2]);
 int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8]);
 /* devices of the handle's group (1 for an ordinary handle) */
 uint32_t mi355rt_device_count(const mi355rt_handle* h);
+/* measurement hook behind bench.py's roofline (no reference counterpart): the rate at which the device's vector memory pipe serves
+ * the trace kernels' kind of fetch and nothing else — every lane of 8 waves per SIMD walks `steps` random 32-byte nodes of an
+ * L2-resident table of table_nodes nodes with two 16-byte loads per node (profiles/r03_notes.md).  out[0] cache-line accesses per
+ * second (one per lane and load), out[1] kernel time in ms, out[2] node fetches per second. */
+int mi355rt_debug_gather_rate(mi355rt_handle* h, uint32_t table_nodes, uint32_t steps, double out[3]);
 /* test hook: with MI355RT_DEBUG_GUARD set in the environment every pass buffer is allocated with a 256-byte tail of 0xA5;
  * this returns how many of those bytes a launch has overwritten (0 = nothing wrote past a buffer; -1: error) */
 int64_t mi355rt_debug_check_guards(mi355rt_handle* h);

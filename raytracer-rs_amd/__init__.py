@@ -103,6 +103,7 @@ ABI = [
     ("mi355rt_last_error", C.c_char_p, [_H]),
     ("mi355rt_trace_frame_additive", C.c_uint32, [_H]),
     ("mi355rt_render", C.c_int, [_H, C.c_uint32, C.POINTER(RayCounts)]),
+    ("mi355rt_render_async", C.c_int, [_H, C.c_uint32]),
     ("mi355rt_last_counts", C.c_int, [_H, C.POINTER(RayCounts)]),
     ("mi355rt_get_tonemapped_pixels", C.c_int, [_H, _U, C.c_size_t]),
     ("mi355rt_tonemap_owned_rows_device", C.c_int, [_H, C.c_void_p, C.c_size_t]),
@@ -142,6 +143,7 @@ ABI = [
     ("mi355rt_comm_ranks", C.c_uint32, [_H]),
     ("mi355rt_hbm_allocated_bytes", C.c_uint64, [_H]),
     ("mi355rt_debug_check_guards", C.c_int64, [_H]),
+    ("mi355rt_debug_gather_rate", C.c_int, [_H, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     ("mi355rt_width", C.c_uint32, [_H]),
     ("mi355rt_height", C.c_uint32, [_H]),
     ("mi355rt_triangle_count", C.c_uint32, [_H]),
@@ -290,7 +292,11 @@ class RayTracer:
         return out
 
     # --- additions (no reference counterpart)
-    def render(self, spp):
+    def render(self, spp, wait=True):
+        """whole frame (owned stripes) x spp; wait=False only queues it (mi355rt_render_async) and returns None: last_counts() waits"""
+        if not wait:
+            self._check(lib().mi355rt_render_async(self._h, int(spp)))
+            return None
         rc = RayCounts()
         self._check(lib().mi355rt_render(self._h, int(spp), C.byref(rc)))
         return rc
@@ -344,6 +350,12 @@ class RayTracer:
     def comm_ranks(self):
         """ranks of the live RCCL communicator as RCCL counts them (ncclCommCount); 0 without one"""
         return int(lib().mi355rt_comm_ranks(self._h))
+
+    def debug_gather_rate(self, table_nodes=48000, steps=2000):
+        """the device's divergent-gather rate (kernels.hip, gather_rate_kernel): dict(line_accesses_per_s, ms, node_fetches_per_s)"""
+        out = (C.c_double * 3)()
+        self._check(lib().mi355rt_debug_gather_rate(self._h, table_nodes, steps, out))
+        return {"line_accesses_per_s": out[0], "ms": out[1], "node_fetches_per_s": out[2]}
 
     def debug_check_guards(self):
         """MI355RT_DEBUG_GUARD: overwritten guard bytes behind the pass buffers (0 = clean)"""

@@ -122,6 +122,12 @@ int mi355rt_render(mi355rt_handle* h, uint32_t spp, mi355rt_ray_counts* counts)
     return ok ? MI355RT_OK : MI355RT_E_HIP;
 }
 
+int mi355rt_render_async(mi355rt_handle* h, uint32_t spp)
+{
+    if (!h) return MI355RT_E_INVALID;
+    return h->g->render(spp, false) ? MI355RT_OK : MI355RT_E_HIP;
+}
+
 int mi355rt_last_counts(mi355rt_handle* h, mi355rt_ray_counts* counts)
 {
     if (!h || !counts) return MI355RT_E_INVALID;
@@ -294,6 +300,12 @@ int mi355rt_octree_stats(const mi355rt_handle* h, uint32_t out[8])
     return MI355RT_OK;
 }
 uint32_t mi355rt_device_count(const mi355rt_handle* h) { return h ? (uint32_t)h->g->size() : 0u; }
+
+int mi355rt_debug_gather_rate(mi355rt_handle* h, uint32_t table_nodes, uint32_t steps, double out[3])
+{
+    if (!h || !out) return MI355RT_E_INVALID;
+    return h->r->debug_gather_rate(table_nodes, steps, out) ? MI355RT_OK : MI355RT_E_HIP;
+}
 
 int64_t mi355rt_debug_check_guards(mi355rt_handle* h)
 {

@@ -57,10 +57,10 @@ uint32_t DeviceGroup::trace_frame_additive()
     return ret;
 }
 
-bool DeviceGroup::render(uint32_t spp)
+bool DeviceGroup::render(uint32_t spp, bool wait)
 {
     error_.clear();
-    if (devs_.size() == 1) { counts_from_render_ = false; return primary()->render(spp); }
+    if (devs_.size() == 1) { counts_from_render_ = false; return primary()->render(spp, wait); }     // (a group of several devices always waits: its members render on host threads)
     std::vector<char> ok(devs_.size(), 0);
     std::vector<std::thread> th;
     for (size_t i = 0; i < devs_.size(); ++i) th.emplace_back([&, i] { ok[i] = devs_[i]->render(spp) ? 1 : 0; });    // render() waits for its device

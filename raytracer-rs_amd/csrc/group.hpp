@@ -21,7 +21,7 @@ public:
     Renderer* device(size_t i) const { return devs_[i].get(); }
 
     uint32_t trace_frame_additive();
-    bool render(uint32_t spp);
+    bool render(uint32_t spp, bool wait = true);
     bool last_counts(mi355rt_ray_counts& out);
     bool get_tonemapped(uint32_t* out, size_t n);
     bool film_get(float* sum, float* sumsq, uint32_t* n);

@@ -1108,6 +1108,27 @@ hipError_t launch_slab(hipStream_t stream, const float* inv_rays6, const float* 
     return hipGetLastError();
 }
 
+// ---- the roofline of the trace kernels, measured: what the CU's vector memory pipe delivers when it does nothing but the
+// trace kernel's kind of fetch (profiles/r03_notes.md, tools/micro/gather_bench.hip shape A).  Every lane walks a dependent chain
+// of random 32-byte "nodes" of an L2-resident table with the inner step's two 16-byte loads; 8 waves per SIMD, grid = the chip.
+// Each lane touches its own cache line per step: 64 lines per load instruction (rocprofv3: TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD = 64.0).
+__global__ __launch_bounds__(kBlock, 8) void gather_rate_kernel(const uint4* __restrict__ table, uint32_t nnodes, uint32_t steps, uint32_t* sink)
+{
+    const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t node = (ray * 2654435761u) % nnodes, acc = 0u;
+    for (uint32_t s = 0; s < steps; ++s) {
+        const uint4 q0 = table[2u * node], q1 = table[2u * node + 1u];
+        acc += q0.x ^ q1.y;
+        node = (q0.w + q1.w + s * 40503u + ray) % nnodes;              // dependent: the next node comes from the data
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+hipError_t launch_gather_rate(hipStream_t stream, int num_cus, const void* table, uint32_t nnodes, uint32_t steps, uint32_t* sink)
+{
+    hipLaunchKernelGGL(gather_rate_kernel, dim3((unsigned)num_cus * 8u), dim3(kBlock), 0, stream, (const uint4*)table, nnodes, steps, sink);
+    return hipGetLastError();
+}
+
 // ---- Film::get_pixels (film.rs:43-47) and Film::get_estimated_variances (film.rs:51-67) on the device ----
 __global__ __launch_bounds__(256) void film_stat_kernel(int variances, size_t npix, const float* __restrict__ film_sum, const float* __restrict__ film_sumsq,
                                                        const uint32_t* __restrict__ film_n, float* __restrict__ out)

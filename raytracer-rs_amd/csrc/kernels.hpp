@@ -34,6 +34,8 @@ hipError_t launch_place_stripes(hipStream_t stream, const uint32_t* gathered, ui
                                 uint32_t stripe_rows, uint32_t world, uint32_t slot_rows);
 hipError_t launch_slab(hipStream_t stream, const float* inv_rays6, const float* cubes6, uint32_t n, uint8_t* hit, float* tmin);
 hipError_t launch_film_stat(hipStream_t stream, bool variances, size_t npix, const float* film_sum, const float* film_sumsq, const uint32_t* film_n, float* out);
+// the gather microbenchmark behind bench.py's roofline: num_cus * 8 blocks walk `steps` random nodes of `table` each
+hipError_t launch_gather_rate(hipStream_t stream, int num_cus, const void* table, uint32_t nnodes, uint32_t steps, uint32_t* sink);
 hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, uint32_t n, float* q, float* r, float* p);
 
 }  // namespace mi355rt

@@ -684,7 +684,10 @@ bool Renderer::queue_counts_copy()
     return true;
 }
 
-bool Renderer::end_call(uint64_t primary)
+// wait == false (mi355rt_render_async): everything is queued — the slices joined on the main stream, the counters' copy behind them —
+// and the call returns; mi355rt_last_counts / mi355rt_synchronize wait.  Consecutive frames then run back to back on the device
+// instead of one host round trip apart (a few % of a 3 ms frame: one rank's share of a strong-scaled frame).
+bool Renderer::end_call(uint64_t primary, bool wait)
 {
     for (uint32_t i = 1; i < active_slices_; ++i) {          // join the slices on the main stream
         HIP_TRY(hipEventRecord(slices_[i].done, slices_[i].stream));
@@ -693,6 +696,7 @@ bool Renderer::end_call(uint64_t primary)
     active_slices_ = 1;
     HIP_TRY(hipEventRecord(ev_end_, stream_));
     if (!queue_counts_copy()) return false;
+    if (!wait) { counts_pending_ = true; pending_primary_ = primary; pending_timed_ = true; return true; }
     HIP_TRY(hipStreamSynchronize(stream_));
     return fetch_counts(primary, true);
 }
@@ -705,7 +709,8 @@ bool Renderer::last_counts(mi355rt_ray_counts& out)
         if (!bind()) return false;
         HIP_TRY(hipStreamSynchronize(stream_));
         counts_pending_ = false;
-        if (!fetch_counts(pending_primary_, false)) return false;
+        const bool timed = pending_timed_; pending_timed_ = false;
+        if (!fetch_counts(pending_primary_, timed)) return false;
     }
     out = counts;
     return true;
@@ -785,11 +790,11 @@ uint32_t Renderer::trace_frame_additive()
     current_row = win.next_row;
     mark_dirty_window(win.first, win.total);
     if (!queue_counts_copy()) return 0;
-    counts_pending_ = true; pending_primary_ = (uint64_t)win.total * cfg.width;
+    counts_pending_ = true; pending_primary_ = (uint64_t)win.total * cfg.width; pending_timed_ = false;
     return 50u * cfg.width;
 }
 
-bool Renderer::render(uint32_t spp)
+bool Renderer::render(uint32_t spp, bool wait)
 {
     if (!begin_call()) return false;
     const uint32_t nrows = (uint32_t)owned_rows.size();
@@ -862,7 +867,7 @@ bool Renderer::render(uint32_t spp)
         }
     }
     for (uint32_t r : owned_rows) ldr_dirty_[r] = 1;
-    return end_call((uint64_t)nrows * cfg.width * spp);
+    return end_call((uint64_t)nrows * cfg.width * spp, wait);
 }
 
 // get_tonemapped_pixels, mod.rs:120-128.  The reference maps the whole film on every call although one
@@ -1048,6 +1053,39 @@ bool Renderer::debug_numerics(const float* a, const float* b, size_t n, float* q
     chk(hipStreamSynchronize(stream_), "sync");
     (void)hipFree(d);
     return ok;
+}
+
+// mi355rt_debug_gather_rate: the divergent-gather rate of this device's vector memory pipe (kernels.hip, gather_rate_kernel).
+// out[0] = cache-line accesses per second (64 lanes x 2 loads per wave-step, each lane on its own line), out[1] = kernel ms,
+// out[2] = 32-byte node fetches per second.
+bool Renderer::debug_gather_rate(uint32_t table_nodes, uint32_t steps, double out[3])
+{
+    if (!bind()) return false;
+    if (table_nodes < 1024 || steps == 0) { last_error = "bad debug_gather_rate arguments"; return false; }
+    std::vector<uint32_t> host((size_t)table_nodes * 8);
+    uint32_t x = 12345u;
+    for (uint32_t& v : host) { x = x * 1664525u + 1013904223u; v = x >> 8; }
+    void* d = nullptr; uint32_t* sink = nullptr;
+    HIP_TRY(hipMalloc(&d, host.size() * 4));
+    bool ok = true;
+    auto chk = [&](hipError_t e, const char* w) { if (ok && e != hipSuccess) ok = fail(e, w); };
+    chk(hipMalloc((void**)&sink, 4), "hipMalloc");
+    chk(hipMemcpy(d, host.data(), host.size() * 4, hipMemcpyHostToDevice), "upload table");
+    float best = 0.0f;
+    for (int rep = 0; ok && rep < 3; ++rep) {                          // first launch warms the caches and the clocks
+        chk(hipEventRecord(ev_begin_, stream_), "event");
+        chk(launch_gather_rate(stream_, num_cus_, d, table_nodes, steps, sink), "gather kernel");
+        chk(hipEventRecord(ev_end_, stream_), "event");
+        chk(hipStreamSynchronize(stream_), "sync");
+        float ms = 0.0f;
+        if (ok) chk(hipEventElapsedTime(&ms, ev_begin_, ev_end_), "elapsed");
+        if (rep > 0 && (best == 0.0f || ms < best)) best = ms;
+    }
+    (void)hipFree(d); if (sink) (void)hipFree(sink);
+    if (!ok || best <= 0.0f) return false;
+    const double wave_steps = (double)num_cus_ * 8.0 * 4.0 * steps;
+    out[0] = wave_steps * 128.0 / (best * 1e-3); out[1] = best; out[2] = wave_steps * 64.0 / (best * 1e-3);
+    return true;
 }
 
 bool Renderer::debug_slab(const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin)

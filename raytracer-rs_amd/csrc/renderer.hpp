@@ -20,7 +20,7 @@ public:
     ~Renderer();
 
     uint32_t trace_frame_additive();                                   // mod.rs:80-117
-    bool render(uint32_t spp);
+    bool render(uint32_t spp, bool wait = true);                        // wait == false: queued only (mi355rt_render_async)
     bool get_tonemapped(uint32_t* out, size_t n);                       // mod.rs:120-128
     bool tonemap_owned_rows_device(uint32_t* device_out, size_t n, hipStream_t caller_stream = nullptr);
     bool last_counts(mi355rt_ray_counts& out);
@@ -47,6 +47,7 @@ public:
     uint32_t comm_ranks();                                              // ncclCommCount of the live communicator, 0 without one
     long check_guards();                                                // MI355RT_DEBUG_GUARD: corrupted guard bytes behind the pass buffers
     size_t hbm_allocated_bytes() const;                                 // device memory this handle holds (scene, film, pass buffers, gather slots)
+    bool debug_gather_rate(uint32_t table_nodes, uint32_t steps, double out[3]);
     bool debug_slab(const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
     bool film_stat(bool variances, float* rgb);
     bool debug_numerics(const float* a, const float* b, size_t n, float* q, float* r, float* p);
@@ -114,7 +115,7 @@ private:
     void describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32_t row_wrap, uint32_t npix, size_t nsamples, uint32_t chunk,
                        bool explicit_sample, uint32_t epixel, uint32_t esample) const;
     bool begin_call();
-    bool end_call(uint64_t primary);
+    bool end_call(uint64_t primary, bool wait = true);
     bool fetch_counts(uint64_t primary, bool timed_call);
     bool queue_counts_copy();
     void mark_dirty_window(uint32_t first, uint32_t total);
@@ -145,6 +146,7 @@ private:
     void* comm_ = nullptr;               // ncclComm_t
     bool counts_pending_ = false;        // the last call was an asynchronous 50-row frame: counters not fetched yet
     uint64_t pending_primary_ = 0;
+    bool pending_timed_ = false;         // the pending call was a whole frame: its HIP-event time is read with the counters
     DCounters* d_counters_ = nullptr;
     DCounters* h_counters_ = nullptr;    // pinned host mirror (queue_counts_copy)
     float* d_debug_color_ = nullptr;
