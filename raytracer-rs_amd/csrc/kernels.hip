@@ -358,14 +358,14 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                                                  add3(rs.o, vscale(rs.d, rs.t)));
                     if (rs.occ < 0) {                                           // radiance ray
                         st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), hit ? rs.prim : kMiss);
-                        if (hit) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
+                        if (hit) st4<1>((float4*)((char*)hits + ((size_t)rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
                     } else if (hit && rs.t > 0.01f && rs.t < 1.0f) {              // shadow ray (rec: its term), blocked (mod.rs:226-232)
                         store_blocked(slot_L, rec);
                     }
                 } else
                 if (CONFIRM || rs.occ < 0) {                                    // radiance ray (CONFIRM: every ray)
                     st1<1>((uint32_t*)((char*)ps.hit_prim + (rec << 2)), rs.prim);     // 4 B for every ray, the 16 B record only for hits
-                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + (rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
+                    if (rs.prim != kMiss) st4<1>((float4*)((char*)hits + ((size_t)rec << 4)), make_float4(rs.t, rs.u, rs.v, __uint_as_float(rs.prim)));
                 } else if (rs.occ == 1) {                              // blocked, mod.rs:232
                     store_blocked(slot_L, rec);
                 }
@@ -409,15 +409,15 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     primary_sample(cam, ps, film_n, w_chunk * ps.chunk + i, pixel, sampleno, o, d);
                     rec = w_chunk * ps.region + i;
                 } else {
-                    // record index and byte offsets in 32 bits (records * 16 < 2^32: renderer.cpp); the three
-                    // planes of the queue are wave-uniform base pointers
+                    // record index in 32 bits, byte offsets in 64 (a whole 1080p x 64 spp frame in ONE pass is 531 M records of 16 B per plane);
+                    // the planes of the queue are wave-uniform base pointers
                     shadow = i >= w_nrad;
                     const uint32_t r = w_chunk * ps.region + (shadow ? ps.region - 1u - (i - w_nrad) : i);
                     const char* __restrict__ p0 = (const char*)in_q;
                     const char* __restrict__ p1 = (const char*)(in_q + ps.qstride);
-                    const float4 r0 = ld4<0>((const float4*)(p0 + (r << 4)));
+                    const float4 r0 = ld4<0>((const float4*)(p0 + ((size_t)r << 4)));
                     float4 r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (!shadow) r1 = ld4<0>((const float4*)(p1 + (r << 4)));                      // a shadow record has no second plane
+                    if (!shadow) r1 = ld4<0>((const float4*)(p1 + ((size_t)r << 4)));                      // a shadow record has no second plane
                     rec = r;
                     if (shadow) {
                         shadow_ray_of(sc, ps, r0, o, d);
@@ -442,7 +442,12 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
         for (int u = 0; u < kInnerStepsPerIteration; ++u) {
             if (__ballot(lane_at_inner(rs)) == 0ull) break;
             inner_pred<COUNT>(sc, rs, stack, kBlock, acc_nodes, COUNT ? acc_below : nullptr);
-            if (COUNT) ++acc_ie;
+            if (COUNT) {
+                ++acc_ie;
+                // instrumented builds check what the shipped loop takes from the host (renderer.cpp: BVH depth <= kBvhMaxDepth, stack rows = depth + 2):
+                // a push writes row sp + 1 of stack_depth + 1 rows.  The call then fails with "traversal stack overflow" instead of walking on garbage.
+                if (__ballot(rs.sp >= (int)ps.stack_depth) != 0ull && lane_id() == 0) atomicOr(&counters->overflow, 2u);
+            }
         }
         const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))

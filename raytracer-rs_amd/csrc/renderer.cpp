@@ -441,8 +441,8 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
     }
     const size_t nchunks = (nsamples + chunk_ - 1) / chunk_;
     const size_t records = nchunks * chunk_ * records_per_sample_;
-    // the kernels index light-term floats with 32 bits and address hit / ray records with 32-bit BYTE offsets (16 B each)
-    if (nsamples > 0x7FFFFFFFull || records > 0x0FFFFFFFull || nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 3ull > 0xFFFFFFFFull) {
+    // the kernels index records, light-term floats and hit flags with 32 bits (byte offsets are 64-bit)
+    if (nsamples > 0x7FFFFFFFull || records > 0x3FFFFFFFull || nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 3ull > 0xFFFFFFFFull) {
         last_error = "pass too large"; alloc_failed_ = true; return false;     // the caller retries with a smaller pass
     }
     // (n_radiance, n_shadow) per chunk: the fused 50-row launch cuts the same samples into chunks as small as kMinChunk
@@ -673,7 +673,7 @@ bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
     counts.trace_ms = tms; counts.trace_secondary_ms = sms; counts.trace_secondary_launches = nsec;
     // s_memtime ticks are shader cycles, s_memrealtime ticks 10 ns: the clock the trace waves ran at (COUNT builds stamp both)
     counts.shader_clock_mhz = c.t_sum_real ? (double)c.t_sum_cycles / (double)c.t_sum_real * 100.0 : 0.0;
-    if (c.overflow) { last_error = "internal: ray queue overflow"; return false; }
+    if (c.overflow) { last_error = (c.overflow & 2u) ? "internal: traversal stack overflow (instrumented build: a ray held more deferred nodes than the stack has rows)" : "internal: ray queue overflow"; return false; }
     return true;
 }
 
@@ -805,7 +805,10 @@ bool Renderer::render(uint32_t spp, bool wait)
         if (!slices_explicit) nsl = (uint32_t)std::min<uint64_t>(nsl, std::max<uint64_t>(1, (uint64_t)nrows * cfg.width * spp >> 25));
         nsl = std::min(nsl, (nrows + cfg.stripe_rows - 1) / cfg.stripe_rows);
         if (!assign_slice_rows(nsl)) return false;
-        size_t target = (size_t)48 << 20;                               // samples per pass of one slice
+        // samples per pass of one slice: 144 Mi — the whole 1080p x 64 spp frame in ONE pass (55 GB of pass buffers).  Every pass costs
+        // its launches' ramps and tails: 3 passes of 44 M samples 22.9 ms, 2 passes 22.2-22.6 ms, 1 pass 21.6 ms (profiles/r03_notes.md,
+        // with the HBM each takes: 18.9 / 27.4 / 54.5 GB); MI355RT_PASS_SAMPLES or config.samples_per_pass trade the memory back.
+        size_t target = (size_t)144 << 20;
         if (const char* e = getenv("MI355RT_PASS_SAMPLES")) { long v = atol(e); if (v >= 1024) target = (size_t)v; }
         // The pass buffers (two ray queues, hit records, light terms: ~410 B per sample) are sized for the
         // largest pass.  If the device cannot hold them (another tenant, a 16 GB part), halve the pass and

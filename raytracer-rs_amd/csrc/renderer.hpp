@@ -62,7 +62,8 @@ public:
     Bvh bvh;
     uint32_t ntri = 0;
     uint32_t current_row = 0;
-    uint32_t slices = 3;                  // concurrent frame slices of render() (1..8), MI355RT_SLICES / mi355rt_set_slices
+    uint32_t slices = 1;                  // concurrent frame slices of render() (1..8), MI355RT_SLICES / mi355rt_set_slices.  Round 2 ran 3: they filled the
+                                          // tails of each other's trace launches; with the tail chunks handed out in parts one slice is as fast and holds a third of the memory
     bool slices_explicit = false;         // set through the API: used as given, also for small frames
     uint32_t nodes_per_sample = 1;
     uint32_t level_first[kMaxLevels + 1] = { 0 };

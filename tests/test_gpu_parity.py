@@ -521,6 +521,40 @@ def test_4k_frame_tiled_over_8_stripes_matches_oracle_on_sampled_rows(pkg, scene
             assert np.array_equal(bits(s_).reshape(h, w, 3)[r0], bits(os_).reshape(h, w, 3)[r0])
 
 
+def test_c5_one_rank_share_at_full_size(pkg, scenes, oracle):
+    """BASELINE config 5 AT ITS SIZE, as far as one GPU goes: thai2 3840x2160 x 256 spp dealt to 8 ranks in the 2-row stripes
+    bench.py deals; rank 5's share (270 rows, 265 M primary samples, ~550 M rays) is rendered twice.  Every owned pixel holds 256
+    samples and no other pixel any; the ray counters obey the recursion's identities (RECURSIONS = 2 / SUB_SPREAD = 1: a level-0
+    hit emits 2 reflection rays, a level-1 hit 1, every shaded hit at most one shadow ray); the two runs agree bit for bit; and
+    three owned rows — one per third of the image — equal the oracle rendering just those rows at 256 spp."""
+    w, h, spp, rank, world, sr = 3840, 2160, 256, 5, 8, 2
+    rt = make(pkg, scenes, "thai2", w, h, seed=1, stripe_rows=sr, stripe_rank=rank, stripe_world=world)
+    c = rt.render(spp)
+    owned = rt.owned_rows()
+    assert owned.size == 270 and np.all((owned // sr) % world == rank)
+    assert c.primary == owned.size * w * spp == 265420800
+    assert 0 < c.primary_hits <= c.primary - c.primary_culled
+    assert 2 * c.primary_hits <= c.bounce <= 4 * c.primary_hits            # 2 per level-0 hit + 1 per level-1 hit (at most one per level-1 ray)
+    assert 0 < c.shadow <= c.primary_hits + c.bounce                       # at most one per shaded hit of any level
+    s1, q1, n1 = rt.film.pixel_datas()
+    n = n1.reshape(h, w)
+    assert np.all(n[owned] == spp) and int(n.sum(dtype=np.int64)) == owned.size * w * spp
+    assert rt.hbm_allocated_bytes() < 80 * 2**30
+    rt.film.clear()
+    c2 = rt.render(spp)
+    assert (c2.primary, c2.bounce, c2.shadow, c2.primary_hits, c2.primary_culled) == (c.primary, c.bounce, c.shadow, c.primary_hits, c.primary_culled)
+    s2, q2, n2 = rt.film.pixel_datas()
+    assert np.array_equal(n1, n2) and np.array_equal(bits(s1), bits(s2)) and np.array_equal(bits(q1), bits(q2))     # run to run
+    del s2, q2, n2
+    orc = oracle.Oracle(scenes("thai2"), w, h, seed=1)
+    for r0 in (owned[20], owned[135], owned[250]):
+        orc.render(spp, nthreads=16, rows=(int(r0), int(r0) + 1))
+        os_, oq, on = orc.film()
+        assert np.all(on.reshape(h, w)[r0] == spp)
+        assert np.array_equal(bits(s1).reshape(h, w, 3)[r0], bits(os_).reshape(h, w, 3)[r0]), r0
+        assert np.array_equal(bits(q1).reshape(h, w, 3)[r0], bits(oq).reshape(h, w, 3)[r0]), r0
+
+
 def _random_scene(scenes, ntri, seed):
     """ntri small random triangles in a slab in front of the 4boxes camera (materials / light from 4boxes)."""
     rng = np.random.default_rng(seed)

@@ -29,6 +29,6 @@ for combo in itertools.product(*sweeps) if sweeps else [()]:
             rt.film.clear()
             t = time.time(); c = rt.render(64); ts.append(time.time() - t)
         ts.sort()
-        out.append("N=%d share: min %.3f med %.3f ms (gpu %.3f)" % (world, ts[0] * 1e3, ts[len(ts) // 2] * 1e3, c.total_ms))
+        out.append("N=%d share: min %.3f med %.3f ms (gpu %.3f; %.1f GB HBM)" % (world, ts[0] * 1e3, ts[len(ts) // 2] * 1e3, c.total_ms, rt.hbm_allocated_bytes() / 1e9))
         del rt
     print(" ".join("%s=%s" % kv for kv in combo) or "default", "|", " | ".join(out), flush=True)
