@@ -2,6 +2,7 @@
 #include "bvh.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <queue>
 #include <cstdlib>
@@ -108,6 +109,103 @@ struct Builder {
     }
 };
 
+// ---- insertion-based optimisation of the finished binary tree (after Bittner, Hapala, Havran: "Fast insertion-based optimization of
+// bounding volume hierarchies", 2013).  The trace kernels are bound by the cache lines their node fetches touch (profiles/r03_notes.md),
+// i.e. by the number of nodes a ray visits, and the top-down binned build leaves overlap that a local search removes: every subtree N is
+// cut out (its parent is spliced out) and put back where the inner-node surface of the whole tree grows least — a branch-and-bound search
+// from the root, bounded by the surface the insertion costs the ancestors.  Putting N back beside its old sibling is always a candidate,
+// so a move never makes the tree worse.  The deepest leaf may not get deeper than it was (the traversal stack is sized for it).
+struct TreeOptimizer {
+    std::vector<TmpNode>& t;
+    std::vector<int32_t> parent;
+    std::vector<uint8_t> height;          // of the subtree: 0 for a leaf
+    int32_t root;
+    uint32_t dmax;                        // deepest leaf allowed
+
+    static float area(const Box& b) { return b.half_area(); }
+    static Box merged(const Box& a, const Box& b) { Box r = a; r.grow(b); return r; }
+
+    TreeOptimizer(std::vector<TmpNode>& tmp, int32_t r) : t(tmp), parent(tmp.size(), -1), height(tmp.size(), 0), root(r), dmax(0)
+    {
+        // children follow their parent in the array (the builder appends depth-first): one backward sweep gives the heights
+        for (size_t i = 0; i < t.size(); ++i) if (t[i].left >= 0) { parent[t[i].left] = (int32_t)i; parent[t[i].right] = (int32_t)i; }
+        for (size_t i = t.size(); i-- > 0;) {
+            if (t[i].left >= 0) height[i] = (uint8_t)(1 + std::max(height[t[i].left], height[t[i].right]));
+            else dmax = std::max(dmax, t[i].depth);
+        }
+    }
+    void refit_up(int32_t n)
+    {
+        for (; n >= 0; n = parent[n]) {
+            t[n].box = merged(t[t[n].left].box, t[t[n].right].box);
+            height[n] = (uint8_t)(1 + std::max(height[t[n].left], height[t[n].right]));
+        }
+    }
+    double inner_area() const { double a = 0; for (const TmpNode& n : t) if (n.left >= 0) a += area(n.box); return a; }
+
+    bool reinsert(int32_t N)
+    {
+        const int32_t P = parent[N];
+        if (P < 0) return false;
+        const int32_t G = parent[P];
+        if (G < 0) return false;                                  // children of the root stay
+        const int32_t S = t[P].left == N ? t[P].right : t[P].left;
+        // cut N out: the sibling takes the parent's place
+        (t[G].left == P ? t[G].left : t[G].right) = S; parent[S] = G;
+        refit_up(G);
+        // branch and bound for the node X beside which N costs least
+        struct Item { float induced; int32_t node; uint32_t depth; bool operator<(const Item& o) const { return induced > o.induced; } };
+        std::priority_queue<Item> q;
+        q.push(Item{ 0.0f, root, 0u });
+        const float area_n = area(t[N].box);
+        float best = 3.4e38f; int32_t best_x = S;
+        while (!q.empty()) {
+            const Item it = q.top(); q.pop();
+            if (it.induced + area_n >= best) break;               // nothing left in the queue can beat the best
+            const int32_t X = it.node;
+            const float direct = area(merged(t[X].box, t[N].box));
+            const float total = it.induced + direct;
+            if (total < best && it.depth + 1u + std::max(height[X], height[N]) <= dmax) { best = total; best_x = X; }
+            if (t[X].left >= 0) {
+                const float child_induced = total - area(t[X].box);          // what X itself grows by if N goes below it
+                if (child_induced + area_n < best) { q.push(Item{ child_induced, t[X].left, it.depth + 1u }); q.push(Item{ child_induced, t[X].right, it.depth + 1u }); }
+            }
+        }
+        // put N back beside best_x, re-using P as their parent
+        const int32_t X = best_x, Q = parent[X];
+        t[P].left = X; t[P].right = N; parent[X] = P; parent[N] = P; parent[P] = Q;
+        if (Q >= 0) (t[Q].left == X ? t[Q].left : t[Q].right) = P; else root = P;
+        refit_up(P);
+        return X != S;
+    }
+    // depth of every node again (the flattening reads TmpNode::depth of the leaves)
+    void assign_depths()
+    {
+        std::vector<int32_t> stack(1, root);
+        t[root].depth = 0;
+        while (!stack.empty()) {
+            const int32_t n = stack.back(); stack.pop_back();
+            if (t[n].left < 0) continue;
+            t[t[n].left].depth = t[n].depth + 1; t[t[n].right].depth = t[n].depth + 1;
+            stack.push_back(t[n].left); stack.push_back(t[n].right);
+        }
+    }
+    int32_t run(int passes)
+    {
+        std::vector<int32_t> cand;
+        for (int pass = 0; pass < passes; ++pass) {
+            cand.clear();
+            for (size_t i = 0; i < t.size(); ++i) if ((int32_t)i != root && parent[i] >= 0 && parent[parent[i]] >= 0) cand.push_back((int32_t)i);
+            std::sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { const float x = area(t[a].box), y = area(t[b].box); return x != y ? x > y : a < b; });   // large subtrees first
+            size_t moved = 0;
+            for (int32_t n : cand) if (parent[n] >= 0 && parent[parent[n]] >= 0) moved += reinsert(n) ? 1u : 0u;
+            if (moved * 200 < cand.size()) break;                  // < 0.5 % of the nodes moved: converged
+        }
+        assign_depths();
+        return root;
+    }
+};
+
 int32_t leaf_code(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
 // float -> binary16 bit pattern, rounded toward -inf (up == false) or +inf (up == true)
@@ -177,6 +275,18 @@ void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, 
     std::memcpy(out.scene_min, scene.mn, 12); std::memcpy(out.scene_max, scene.mx, 12);
     b.tmp.reserve(2 * (size_t)ntri);
     int32_t root = b.build(0, ntri, 0);
+    {   // MI355RT_BVH_OPT = passes of the insertion-based optimisation (0: the tree as built).  Measured on thai2 (profiles/r03_notes.md): 0 / 1 / 2 / 4
+        // passes -> inner-node surface 100 / 94.3 / 92.8 / 92.3 %, 18.93 / 18.90 / 18.70 / 18.42 node visits per traced ray, 21.68 / 21.52 / 21.24 /
+        // 21.05 ms per frame, 10 / 46 / 82 / 151 ms of build time inside create.  A pass costs ~1 us per node on one host thread, so large scenes get fewer.
+        int passes = ntri <= 32768u ? 4 : ntri <= 65536u ? 2 : ntri <= 131072u ? 1 : 0;
+        if (const char* e = std::getenv("MI355RT_BVH_OPT")) passes = std::max(0, std::min(8, std::atoi(e)));
+        if (passes > 0 && b.tmp[root].left >= 0) {
+            TreeOptimizer opt(b.tmp, root);
+            const double before = opt.inner_area();
+            root = opt.run(passes);
+            if (std::getenv("MI355RT_DEBUG_BVH")) fprintf(stderr, "[mi355rt] BVH optimisation: inner-node surface %.6g -> %.6g (%.1f %%), deepest leaf <= %u\n", before, opt.inner_area(), 100.0 * opt.inner_area() / before, opt.dmax);
+        }
+    }
 
     // Conservative padding: the exact (unfused f32) triangle test decides hits; a box test must
     // never reject a ray the triangle test would accept, so every box is grown by `pad`.
