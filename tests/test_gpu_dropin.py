@@ -310,3 +310,34 @@ def test_no_launch_writes_past_a_pass_buffer(pkg, scenes, monkeypatch):
     rt.set_slices(3)
     rt.render(4)
     assert rt.debug_check_guards() == 0
+
+
+def test_render_async_is_the_same_frame_queued(pkg, scenes):
+    """mi355rt_render_async queues the frame and returns; last_counts / any read-out waits.  Two queued frames + a read-out give the
+    film and the counters of two synchronous frames, bit for bit; a queued frame followed by film.clear() and another queued frame
+    is ordered on the handle's stream."""
+    a = make(pkg, scenes, "ico2", 320, 200, seed=3)
+    b = make(pkg, scenes, "ico2", 320, 200, seed=3)
+    ca = [a.render(3), a.render(2)]
+    assert b.render(3, wait=False) is None and b.render(2, wait=False) is None
+    cb = b.last_counts()                                                   # waits; the counters of the LAST call
+    assert (cb.primary, cb.bounce, cb.shadow, cb.primary_hits) == (ca[1].primary, ca[1].bounce, ca[1].shadow, ca[1].primary_hits)
+    assert cb.total_ms > 0
+    (sa, qa, na), (sb, qb, nb) = a.film.pixel_datas(), b.film.pixel_datas()
+    assert np.array_equal(na, nb) and int(na.max()) == 5
+    assert np.array_equal(bits(sa), bits(sb)) and np.array_equal(bits(qa), bits(qb))
+    b.film.clear(); b.render(4, wait=False); b.film.clear(); b.render(1, wait=False)
+    a.film.clear(); a.render(1)
+    assert np.array_equal(a.get_tonemapped_pixels(), b.get_tonemapped_pixels())
+    assert np.array_equal(bits(a.film.pixel_datas()[0]), bits(b.film.pixel_datas()[0]))
+
+
+def test_gather_rate_hook_reports_a_plausible_rate(pkg, scenes):
+    """mi355rt_debug_gather_rate (bench.py's roofline peak): 64 lanes x 2 loads per wave-step, every lane on its own line.  An MI355X
+    serves a few hundred G of those per second; the node rate is half the access rate by construction."""
+    rt = make(pkg, scenes, "4boxes", 64, 64, seed=1)
+    g = rt.debug_gather_rate(48000, 500)
+    assert 5e10 < g["line_accesses_per_s"] < 5e12 and g["ms"] > 0
+    assert abs(g["line_accesses_per_s"] / g["node_fetches_per_s"] - 2.0) < 1e-9
+    with pytest.raises(RuntimeError):
+        rt.debug_gather_rate(10, 10)                                       # table too small

@@ -848,3 +848,31 @@ def test_device_lbvh_falls_back_on_one_leaf_scenes_and_builds_large_ones(pkg, sc
         assert np.array_equal(d_prim, h_prim) and np.array_equal(bits(d_tuv[d_prim != 0xFFFFFFFF]), bits(h_tuv[h_prim != 0xFFFFFFFF]))
         dev.render(1); host.render(1)
         assert np.array_equal(bits(dev.film.pixel_datas()[0]), bits(host.film.pixel_datas()[0]))
+
+
+def test_bvh_optimisation_changes_the_tree_not_the_answers(pkg, scenes, oracle, monkeypatch):
+    """The host BVH is post-optimised by subtree re-insertion (csrc/bvh.cpp, MI355RT_BVH_OPT passes).  Any conservative tree gives the
+    same hits: closest hits of random rays and a rendered film are identical with 0 and with 4 passes (and equal to the oracle), the
+    optimised tree holds the same triangles in no more nodes and is no deeper."""
+    rng = np.random.default_rng(5)
+    sc = scenes("thai2")
+    lo, hi = sc["tri_verts"].reshape(-1, 3).min(0), sc["tri_verts"].reshape(-1, 3).max(0)
+    o = rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), size=(20000, 3)).astype(np.float32)
+    d = (rng.uniform(lo, hi, size=(20000, 3)) - o).astype(np.float32)
+    rays = np.concatenate([o, d], axis=1)
+    res = {}
+    for passes in ("0", "4"):
+        monkeypatch.setenv("MI355RT_BVH_OPT", passes)
+        rt = make(pkg, scenes, "thai2", 96, 64, seed=2, flags=pkg.FLAG_TRUE_CLOSEST_HIT)
+        st = rt.accel_stats()
+        tuv, prim = rt.intersect_rays(rays)
+        c = rt.render(2)
+        res[passes] = (st, prim.copy(), bits(tuv).copy(), bits(rt.film.pixel_datas()[0]).copy(), (c.primary, c.bounce, c.shadow))
+    (s0, p0, t0, f0, c0), (s4, p4, t4, f4, c4) = res["0"], res["4"]
+    assert s4["nodes"] == s0["nodes"] and s4["leaves"] == s0["leaves"] and s4["max_depth"] <= s0["max_depth"]
+    assert (p0 != 0xFFFFFFFF).mean() > 0.2
+    hit = p0 != 0xFFFFFFFF
+    assert np.array_equal(p0, p4) and np.array_equal(t0[hit], t4[hit]) and np.array_equal(f0, f4) and c0 == c4
+    orc = oracle.Oracle(sc, 96, 64, seed=2, flags=oracle.FLAG_BRUTE_FORCE)
+    orc.render(2, nthreads=8)
+    assert np.array_equal(f4, bits(orc.film()[0]))
