@@ -392,6 +392,15 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         sys.exit(self_launch(args, argv))
 
+    # stdout carries ONE line, the JSON: everything else that writes to file descriptor 1 from here on (RCCL's version banner, gloo's
+    # connection messages, a library's printf) goes to stderr; emit() writes the line to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -429,7 +438,7 @@ def main(argv=None):
     scene = scene_io.load_scene_file(os.path.join(ge.SCENES, args.scene + ".scene"))
     if args.mode == "dropin":
         out = dropin_measure(args, ge, pkg, scene, pmc, pmc_note, full=True)
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
 
     ctx = Ctx()
@@ -626,7 +635,7 @@ def main(argv=None):
             out["dropin"] = d
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ge, scene, width, height, args.fix_row_index)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
