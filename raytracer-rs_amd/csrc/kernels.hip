@@ -48,6 +48,9 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 #ifndef MI355RT_FUSED_FENCE_AGENT
 #define MI355RT_FUSED_FENCE_AGENT 0
 #endif
+#ifndef MI355RT_PRIMARY_BLOCKS
+#define MI355RT_PRIMARY_BLOCKS 7                // blocks per CU the primary trace kernel is compiled for: 69 VGPRs; 8 blocks = 64 VGPRs + 20 B of scratch, measured in profiles/r03_notes.md
+#endif
 #ifndef MI355RT_CONFIRM_BLOCKS
 #define MI355RT_CONFIRM_BLOCKS 5               // blocks per CU the confirm kernel is compiled for (A/B knob, profiles/r02_notes.md)
 #endif
@@ -474,7 +477,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
 }
 
 template <bool PRIMARY, bool COUNT, bool CONFIRM>
-__global__ __launch_bounds__(kBlock, PRIMARY ? 7 : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
+__global__ __launch_bounds__(kBlock, PRIMARY ? MI355RT_PRIMARY_BLOCKS : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       float4* __restrict__ hits, uint32_t* cursor,
                                                       float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
