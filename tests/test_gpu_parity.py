@@ -876,3 +876,16 @@ def test_bvh_optimisation_changes_the_tree_not_the_answers(pkg, scenes, oracle, 
     orc = oracle.Oracle(sc, 96, 64, seed=2, flags=oracle.FLAG_BRUTE_FORCE)
     orc.render(2, nthreads=8)
     assert np.array_equal(f4, bits(orc.film()[0]))
+
+
+def test_randomised_call_sequences_match_the_oracle(pkg, scenes, oracle):
+    """tools/parity_fuzz.py, 30 cases of a fixed seed: random scene, size, RNG seed, recursion setting, leaf size, semantics, stripes,
+    camera moves and sequences of render / trace_frame_additive / film.clear — films, pixels and counters bit-equal to the oracle.
+    (profiles/r03_notes.md records a 1 000-case run.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("parity_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "parity_fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = np.random.default_rng(3)
+    for _ in range(30):
+        fuzz.one_case(pkg, oracle, scenes, rng, verbose=False)

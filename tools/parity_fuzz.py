@@ -1,0 +1,98 @@
+"""Randomised parity: random scene / size / seed / recursion setting / leaf size / semantics / camera moves / call sequence, the HIP
+path against the CPU oracle bit for bit (film sums, sums of squares, counts, packed pixels, ray counters).  Test infrastructure.
+usage: parity_fuzz.py [cases] [seed]   — prints one line per case, exits 1 on the first difference."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def one_case(pkg, O, scenes, rng, verbose=True):
+    name = rng.choice(["ico2", "4boxes", "ico3_tex", "thai2"], p=[0.35, 0.2, 0.2, 0.25])
+    w, h = int(rng.integers(4, 161)), int(rng.integers(3, 121))
+    seed = int(rng.integers(0, 2**31))
+    rec, spread = [(2, 1), (2, 1), (1, 2), (3, 1), (0, 1), (1, 1), (2, 2)][int(rng.integers(0, 7))]
+    tpl = int(rng.choice([1, 5, 20, 70, 100]))
+    sem = int(rng.integers(0, 3))                       # 0 reference default, 1 true closest hit, 2 default + fixed row index
+    gflags = [0, pkg.FLAG_TRUE_CLOSEST_HIT, pkg.FLAG_FIX_ROW_INDEX][sem]
+    oflags = [0, O.FLAG_BRUTE_FORCE, O.FLAG_FIX_ROW_INDEX][sem]
+    stripes = {}
+    if rng.random() < 0.3:
+        world = int(rng.integers(2, 5)); stripes = dict(stripe_rows=int(rng.choice([1, 2, 4, 8])), stripe_rank=int(rng.integers(0, world)), stripe_world=world)
+    sc = scenes(name)
+    rt = pkg.create_raytracer_from_arrays(sc, tpl, w, h, seed=seed, recursions=rec, spread=spread, flags=gflags, **stripes)
+    orc = O.Oracle(sc, w, h, tris_per_leaf=tpl, recursions=rec, spread=spread, seed=seed, flags=oflags)
+    desc = "%s %dx%d seed %d rec %d spread %d tpl %d sem %d %s" % (name, w, h, seed, rec, spread, tpl, sem, stripes or "")
+    steps = []
+    for _ in range(int(rng.integers(1, 5))):
+        kind = rng.choice(["render", "frame", "move", "clear"], p=[0.4, 0.3, 0.2, 0.1])
+        if kind == "move":
+            dx, dy, dz = (float(x) for x in rng.normal(0, 0.4, 3)); ax, ay = float(rng.normal(0, 0.2)), float(rng.normal(0, 0.2))
+            rt.camera.move_rel(dx, dy, dz); orc.camera_move_rel(dx, dy, dz)
+            rt.camera.add_x_angle(ax); orc.camera_add_x_angle(ax); rt.camera.add_y_angle(ay); orc.camera_add_y_angle(ay)
+            rt.film.clear(); orc.film_clear()               # what the reference's binary does after a camera move (main.rs:116-169)
+        elif kind == "clear":
+            rt.film.clear(); orc.film_clear()
+        elif kind == "render" and not stripes:
+            spp = int(rng.integers(1, 4))
+            c = rt.render(spp); oc = orc.render(spp, nthreads=8)
+            assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"]), (desc, steps, c.as_dict(), oc)
+        elif kind == "render":
+            rt.render(int(rng.integers(1, 3)))              # striped handle: compared on its owned rows below (the oracle renders every row)
+            steps.append("render(striped)")
+            continue
+        else:
+            if stripes:
+                continue
+            assert rt.trace_frame_additive() == orc.trace_frame_additive()
+        steps.append(kind)
+    gs, gq, gn = rt.film.pixel_datas()
+    if stripes:
+        # the oracle has no stripes: render the same number of samples into every row, compare the owned rows only
+        owned = rt.owned_rows()
+        n = gn.reshape(h, w)
+        spp = int(n[owned[0], 0]) if owned.size else 0
+        assert np.all(n[owned] == spp), desc
+        rest = np.setdiff1d(np.arange(h), owned)
+        assert not n[rest].any(), desc
+        orc.film_clear()
+        if spp:
+            orc.render(spp, nthreads=8)
+        os_, oq, on = orc.film()
+        assert np.array_equal(bits(gs).reshape(h, w, 3)[owned], bits(os_).reshape(h, w, 3)[owned]), (desc, steps)
+        assert np.array_equal(bits(gq).reshape(h, w, 3)[owned], bits(oq).reshape(h, w, 3)[owned]), (desc, steps)
+    else:
+        os_, oq, on = orc.film()
+        assert np.array_equal(gn, on), (desc, steps)
+        assert np.array_equal(bits(gs), bits(os_)), (desc, steps)
+        assert np.array_equal(bits(gq), bits(oq)), (desc, steps)
+        assert np.array_equal(rt.get_tonemapped_pixels(), orc.get_tonemapped_pixels()), (desc, steps)
+    if verbose:
+        print("ok  ", desc, steps, flush=True)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    pkg = ge.load_package(); O = ge.load_oracle()
+    import importlib
+    sio = importlib.import_module("raytracer_rs_amd.scene_io")
+    cache = {}
+
+    def scenes(name):
+        if name not in cache:
+            cache[name] = sio.load_scene_file(os.path.join(ge.SCENES, name + ".scene"))
+        return cache[name]
+    rng = np.random.default_rng(seed)
+    for _ in range(cases):
+        one_case(pkg, O, scenes, rng)
+    print("%d cases, all bit-exact" % cases)
+
+
+if __name__ == "__main__":
+    main()
