@@ -1285,6 +1285,24 @@ hipError_t launch_tonemap(hipStream_t stream, const uint32_t* rows, uint32_t row
     return hipGetLastError();
 }
 
+// ---- Film::clear (film.rs:37-41) of the rows a striped handle owns: one launch instead of three whole-film memsets ----
+__global__ __launch_bounds__(256) void film_clear_rows_kernel(const uint32_t* __restrict__ rows, uint32_t nrows, uint32_t width, float* film_sum, float* film_sumsq, uint32_t* film_n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nrows * width) return;
+    const size_t pixel = (size_t)rows[i / width] * width + i % width;
+    film_sum[3 * pixel] = 0.0f; film_sum[3 * pixel + 1] = 0.0f; film_sum[3 * pixel + 2] = 0.0f;
+    film_sumsq[3 * pixel] = 0.0f; film_sumsq[3 * pixel + 1] = 0.0f; film_sumsq[3 * pixel + 2] = 0.0f;
+    film_n[pixel] = 0u;
+}
+hipError_t launch_film_clear_rows(hipStream_t stream, const uint32_t* rows, uint32_t nrows, uint32_t width, float* film_sum, float* film_sumsq, uint32_t* film_n)
+{
+    const size_t n = (size_t)nrows * width;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(film_clear_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rows, nrows, width, film_sum, film_sumsq, film_n);
+    return hipGetLastError();
+}
+
 // ---- multi-GPU gather, last step on the root: packed stripes of every rank -> the full frame -----------------
 // gathered = world slots of slot_rows * width u32; slot r holds rank r's owned rows in ascending order (rows are dealt
 // in stripes of stripe_rows, stripe s to rank s % world: Renderer::init).  One thread per pixel of the frame.

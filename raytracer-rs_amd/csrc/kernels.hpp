@@ -32,6 +32,8 @@ hipError_t launch_intersect(hipStream_t stream, const DScene& sc, uint32_t stack
 // multi-GPU gather on the root: world slots of slot_rows packed rows each -> full frame
 hipError_t launch_place_stripes(hipStream_t stream, const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height,
                                 uint32_t stripe_rows, uint32_t world, uint32_t slot_rows);
+// Film::clear restricted to the listed rows (a striped handle's own rows)
+hipError_t launch_film_clear_rows(hipStream_t stream, const uint32_t* rows, uint32_t nrows, uint32_t width, float* film_sum, float* film_sumsq, uint32_t* film_n);
 hipError_t launch_slab(hipStream_t stream, const float* inv_rays6, const float* cubes6, uint32_t n, uint8_t* hit, float* tmin);
 hipError_t launch_film_stat(hipStream_t stream, bool variances, size_t npix, const float* film_sum, const float* film_sumsq, const uint32_t* film_n, float* out);
 // the gather microbenchmark behind bench.py's roofline: num_cus * 8 blocks walk `steps` random nodes of `table` each
