@@ -71,6 +71,8 @@ struct DPass {
     uint32_t npix;            // pixels in this pass (rows_in_pass * width)
     uint32_t row_group, row_group_shift;   // rows per pixel-tile group of the pass order (a power of two <= 8) and its log2
     uint32_t nsamples;        // npix * samples per pixel in this pass
+    uint32_t spp;             // samples per pixel in this pass
+    uint32_t sample_group;    // consecutive samples of a pixel kept together in the pass order (kernels.hip, sample_of); divides spp
     uint32_t seed;
     uint32_t flags;
     uint32_t recursions, spread;

@@ -219,13 +219,35 @@ __device__ __forceinline__ uint32_t pass_pixel(const DPass& ps, uint32_t width, 
     return pass_row(ps, first_row + y) * width + x;
 }
 
+// Order of the primary samples of a pass: sample gi is sample number s of the pass's p-th pixel, gi = ((s / G) * npix + p) * G + s % G
+// with G = ps.sample_group consecutive samples of a pixel kept together (G divides the pass's samples per pixel):
+//   G = 1 (rounds 1-2): one sample of every pixel, then the next: a wave is an 8x8 (128x2 ...) pixel tile at one sample number.
+//   G = spp: ALL samples of a pixel are consecutive: the 64 lanes of a wave trace 64 samples of one pixel.
+// Lanes that hold samples of the same pixel walk the tree together — their primary rays differ by a sub-pixel jitter, their shadow rays run
+// from one pixel's footprint to the same light — and a fetch whose lanes share cache lines is cheaper on the pipe that bounds the trace
+// kernels; but the work of a chunk gets lumpier (a chunk is all hits or all misses), which costs the tails of the launches.
+// Measured in profiles/r03_notes.md.  The film does not depend on the order: every pixel accumulates its own samples in sample order.
+__device__ __forceinline__ void sample_of(const DPass& ps, uint32_t gi, uint32_t& s, uint32_t& p)
+{
+    const uint32_t G = ps.sample_group, per = ps.npix * G;
+    const uint32_t g = gi / per, r = gi - g * per;
+    p = r / G;
+    s = g * G + (r - p * G);
+}
+__device__ __forceinline__ size_t sample_index(const DPass& ps, uint32_t s, uint32_t p)
+{
+    const uint32_t G = ps.sample_group, g = s / G;
+    return ((size_t)g * ps.npix + p) * G + (s - g * G);
+}
+
 // pixel -> primary ray, mod.rs:93-96 + camera.rs:80-90.  gi = index of the primary sample in the pass.
 __device__ __forceinline__ void primary_sample(const DCamera& cam, const DPass& ps, const uint32_t* __restrict__ film_n, uint32_t gi,
                                                uint32_t& pixel, uint32_t& sampleno, f3& o, f3& d)
 {
     if (ps.use_explicit) { pixel = ps.explicit_pixel; sampleno = ps.explicit_sampleno; }
     else {
-        const uint32_t s = gi / ps.npix, p = gi - s * ps.npix;
+        uint32_t s, p;
+        sample_of(ps, gi, s, p);
         pixel = pass_pixel(ps, cam.width, p);
         sampleno = film_n[pixel] + s;
     }
@@ -251,10 +273,12 @@ __device__ __forceinline__ bool chunk_is_culled(const DCamera& cam, const DPass&
 {
     if (!cam.cull_valid || ps.use_explicit || n == 0u) return false;
     const uint32_t g0 = chunk * ps.chunk, g1 = g0 + n - 1u;
-    if (g0 / ps.npix != g1 / ps.npix) return false;                  // straddles two sample indices
+    uint32_t s0, p0, s1, p1;
+    sample_of(ps, g0, s0, p0); sample_of(ps, g1, s1, p1);
+    if (p1 < p0) return false;                                       // pixel-major order: the chunk straddles two sample indices
     uint32_t fr0, nr0, xa, ya, fr1, nr1, xb, yb;
-    pass_column(ps, cam.width, g0 % ps.npix, fr0, nr0, xa, ya);
-    pass_column(ps, cam.width, g1 % ps.npix, fr1, nr1, xb, yb);
+    pass_column(ps, cam.width, p0, fr0, nr0, xa, ya);
+    pass_column(ps, cam.width, p1, fr1, nr1, xb, yb);
     if (fr0 != fr1) return false;                                    // straddles two row groups
     uint32_t row_lo = 0xFFFFFFFFu, row_hi = 0u;                      // all rows of the group (a superset of the chunk's)
     for (uint32_t y = 0; y < nr0; ++y) { const uint32_t r = pass_row(ps, fr0 + y); row_lo = min(row_lo, r); row_hi = max(row_hi, r); }
@@ -916,7 +940,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
     }
     const int group_lane0 = lane_id() & ~(int)(kResolveLanes - 1u);
     for (uint32_t s0 = 0; s0 < spp; s0 += kResolveLanes) {
-        const uint32_t sl = s0 + j < spp ? sample_slot[(s0 + j) * ps.npix + p] : 0xFFFFFFFFu;
+        const uint32_t sl = s0 + j < spp ? sample_slot[sample_index(ps, s0 + j, p)] : 0xFFFFFFFFu;
         const float* L = slot_L + 3ull * (size_t)sl;       // the slot's entry of plane 0; plane q is 3 * q * nslots floats further
         f3 c = mk3(0.0f, 0.0f, 0.0f);                                   // primary miss: RGB::black(), mod.rs:100
         if (sl != 0xFFFFFFFFu) switch (ps.recursions) {

@@ -493,6 +493,14 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
 {
     ps = DPass{};
     ps.rows = d_rows; ps.row0 = row0; ps.row_wrap = row_wrap; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
+    ps.spp = npix ? (uint32_t)(nsamples / npix) : 1u;
+    // samples of a pixel kept together in the pass order (kernels.hip, sample_of): 2 — thai2 frame 21.1 / 20.7 / 20.7 / 20.9 / 21.5 / 21.6 ms at
+    // 1 / 2 / 4 / 8 / 16 / 64, one rank's share of eight 3.27 / 3.24 / 3.30 / 3.34 / 3.40 / 3.63 ms (profiles/r03_notes.md); the largest divisor of spp <= the wish
+    uint32_t group = 2u;
+    if (const char* e = getenv("MI355RT_SAMPLE_GROUP")) { int v = atoi(e); if (v >= 1) group = (uint32_t)v; }
+    group = std::max(1u, std::min(group, ps.spp));
+    while (ps.spp % group) --group;
+    ps.sample_group = group;
     // tile groups of 8 rows, or of the stripe height when rows are dealt (to ranks and to slices) in blocks of fewer rows: a group
     // that spans two blocks lying far apart in the image makes loose culling rectangles and incoherent tiles
     ps.row_group_shift = 3; while (ps.row_group_shift > 0 && (1u << ps.row_group_shift) > cfg.stripe_rows) --ps.row_group_shift;
