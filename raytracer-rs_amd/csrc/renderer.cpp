@@ -515,6 +515,10 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
     ps.refill_threshold = 24; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
+    // the primary launch refills later: its rays are neighbours on the screen, and the more of them start together the more lanes of a quad
+    // share the lines they fetch (cache-line accesses of the launch at 8 / 24 / 48 / 64 idle lanes: 1.48 / 1.21 / 1.03 / 0.94e10 per 7 frames,
+    // profiles/r03_notes.md); secondary rays do not gain from it (5.8e10 at 24 and at 48)
+    refill_primary_ = 48; if (const char* e = getenv("MI355RT_REFILL_PRIMARY")) { int v = atoi(e); if (v >= 1 && v <= 64) refill_primary_ = (uint32_t)v; }
     ps.pull_mode = 4u;                  // 64 interleaved cursors (see pull_chunk in kernels.hip)
     if (const char* e = getenv("MI355RT_PULL")) ps.pull_mode = (uint32_t)atoi(e);
     ps.pull_group = 1; if (const char* e = getenv("MI355RT_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.pull_group = (uint32_t)v; }
@@ -574,8 +578,11 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
     }
     if (mode_ == kModeOctreeWalk)
         HIP_TRY(launch_trace_octree(tst, num_cus_, r == 0, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_slot_L, d_film_n_));
-    else
-        HIP_TRY(launch_trace(tst, num_cus_, trace_blocks_per_cu, r == 0, count, mode_ == kModeConfirm, dscene_, cam, ps, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
+    else {
+        DPass pr = ps;
+        if (r == 0) pr.refill_threshold = refill_primary_;             // primary rays: see describe_pass
+        HIP_TRY(launch_trace(tst, num_cus_, trace_blocks_per_cu, r == 0, count, mode_ == kModeConfirm, dscene_, cam, pr, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
+    }
     if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], tst)); ev_used_ += 2; }
     ++launches_;
     if (tst != st) { HIP_TRY(hipEventRecord(sl.ev_traced, tst)); HIP_TRY(hipStreamWaitEvent(st, sl.ev_traced, 0)); }

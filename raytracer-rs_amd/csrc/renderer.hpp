@@ -160,6 +160,7 @@ private:
     static constexpr uint32_t kMinChunk = 16;   // smallest chunk any launcher cuts a pass into (the fused 50-row launch: 16 / 32 / 64)
     uint32_t max_level_nodes_ = 1;
     uint32_t leaf_threshold_ = 16;
+    mutable uint32_t refill_primary_ = 48;   // refill threshold of the primary trace launch (describe_pass)
     bool alloc_failed_ = false;          // the last ensure_pass_capacity failure was an out-of-memory
     uint32_t records_per_sample_ = 1;
     uint32_t nlights_ = 0;

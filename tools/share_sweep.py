@@ -23,7 +23,7 @@ for combo in itertools.product(*sweeps) if sweeps else [()]:
             os.environ[k] = v
     out = []
     for world in worlds:
-        rt = pkg.create_raytracer_from_arrays(sc, 70, 1920, 1080, seed=1, stripe_rows=2, stripe_rank=0, stripe_world=world)
+        rt = pkg.create_raytracer_from_arrays(sc, 70, 1920, 1080, seed=1, stripe_rows=int(os.environ.get("SWEEP_STRIPE_ROWS", "2")), stripe_rank=0, stripe_world=world)
         ts = []
         for it in range(7):
             rt.film.clear()
