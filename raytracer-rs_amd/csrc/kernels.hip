@@ -453,6 +453,9 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     } else { o = mk3(r0.x, r0.y, r0.z); d = mk3(r0.w, r1.x, r1.y); }
                 }
                 ray_init(rs, o, d, shadow, sc.root);
+#ifdef MI355RT_EXP_NOSHADOW      // timing experiment (wrong results): shadow rays are not traced at all — what do they cost?
+                if (shadow) rs.node = kNodeFin;
+#endif
             }
             w_next += min((uint32_t)__popcll(idle), avail);
             idle = __ballot(rs.node == kNodeIdle);
@@ -476,6 +479,9 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                 if (__ballot(rs.sp >= (int)ps.stack_depth) != 0ull && lane_id() == 0) atomicOr(&counters->overflow, 2u);
             }
         }
+#ifdef MI355RT_EXP_REDESCEND     // timing experiment (same results): a secondary ray that reaches its FIRST leaf starts over at the root — what does the first descent cost, in place?
+        if (!PRIMARY) { const bool at_leaf = lane_at_leaf(rs); const bool redo = at_leaf & (rs.tri == 0u); rs.tri = at_leaf ? 1u : rs.tri; if (redo) { rs.node = sc.root; rs.sp = 0; } }
+#endif
         const unsigned long long m_leaf = __ballot(lane_at_leaf(rs));
         if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= ps.leaf_threshold || __ballot(lane_at_inner(rs)) == 0ull))
             { leaf_pred<COUNT, CONFIRM || PRIMARY>(sc, rs, stack, kBlock, acc_tris); if (COUNT) ++acc_le; }
