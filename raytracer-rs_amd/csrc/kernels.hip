@@ -695,6 +695,19 @@ __device__ __forceinline__ void hemisphere_walk(const float4* __restrict__ table
     }
 }
 
+#ifndef MI355RT_SORT_BINS
+#define MI355RT_SORT_BINS 8                    // reflection rays of a shading batch grouped by direction: 0 off, 8 octants, 24 octant x dominant axis (A/B knob, profiles/r03_notes.md)
+#endif
+constexpr uint32_t kSortBins = MI355RT_SORT_BINS;
+__device__ __forceinline__ uint32_t dir_bin(const f3 d)
+{
+    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    if (kSortBins <= 8u) return oct;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const uint32_t major = ax >= ay ? (ax >= az ? 0u : 2u) : (ay >= az ? 1u : 2u);
+    return oct * 3u + major;
+}
+
 // ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
 // Shade the hits of one chunk (one wave): see the header of this file.
 // in_nrad: radiance rays of the chunk in in_q (ignored for PRIMARY); out_nrad / out_nshadow: what was appended to out_q.
@@ -737,21 +750,24 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             // reached, must read back as black (mod.rs:99-100, 170)
             // (slot_L is node-major: plane q = node * nlights + light holds the term of every slot, 12 B each, so that the
             // stores of a round — one node level — fill whole cache lines instead of 12 B of every 60)
+            // The planes of node 0 (one per light) are not zeroed here: this wave writes every one of their entries itself below — the term, or the zero.
             const uint32_t planes = ps.nodes_per_sample * sc.nlights, total = cnt * 3u;
-            for (uint32_t q = 0; q < planes; ++q) {
+#ifdef MI355RT_EXP_SHADE_NOZERO
+            for (uint32_t q = planes; q < planes; ++q) {
+#else
+            for (uint32_t q = sc.nlights; q < planes; ++q) {
+#endif
                 float* z = slot_L + 3ull * ((size_t)q * ps.nslots + (size_t)chunk * ps.chunk);     // 16-byte aligned: nslots and ps.chunk are multiples of 4
                 float4* z4 = (float4*)z;
                 for (uint32_t k = (uint32_t)lane; k < total / 4u; k += 64u) st4<2>(&z4[k], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 for (uint32_t k = (total & ~3u) + (uint32_t)lane; k < total; k += 64u) z[k] = 0.0f;
             }
-            // the terms of this chunk's level-0 nodes are written below, by other lanes of this wave, to the addresses just zeroed:
-            // the zeroes must have left the wave first (workgroup scope = wait for the stores, nothing is flushed)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t out_front = 0u, out_back = 0u, dropped = 0u;
         for (uint32_t j = 0; j < cnt; j += 64u) {
             bool active = j + (uint32_t)lane < cnt;
+            const bool in_batch = active;                      // PRIMARY: owns the light-term slot chunk * ps.chunk + j + lane, shaded or not
             f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), hp = mk3(0, 0, 0), n = mk3(0, 0, 1);
             uint32_t slot = 0u, node = 0u, pixel = 0u, sampleno = 0u, geom = 0u;
             float4 h = make_float4(0, 0, 0, 0);
@@ -771,7 +787,9 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                 if (PRIMARY && level < ps.recursions) ps.slot_ps[slot] = make_uint2(pixel, sampleno);   // what the deeper levels hash with
                 if (WALK) {
                     float wt = h.x, wu = h.y, wv = h.z; uint32_t wprim = __float_as_uint(h.w);
+#ifndef MI355RT_EXP_SHADE_NOWALK     // timing experiments (wrong picture): what do the parts of the shade kernels cost?
                     confirm_walk(sc, o, d, wt, wu, wv, wprim);
+#endif
                     h = make_float4(wt, wu, wv, __uint_as_float(wprim));
                     active = wprim != kMiss;
                 }
@@ -804,6 +822,9 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                     }
                 }
                 uint32_t n_new;
+#ifdef MI355RT_EXP_SHADE_NOLIGHT
+                want = false;
+#endif
                 const uint32_t oi = wave_append(want, out_back, n_new);
                 if (want && out_front + oi < ps.region) {
                     const size_t r = base + (ps.region - 1u - oi);
@@ -811,10 +832,18 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                     st4<2>(&out_q[r], make_float4(hp.x, hp.y, hp.z, __uint_as_float(term)));
                     float* dst = slot_L + term;                    // optimistic: whoever finds the shadow ray blocked zeroes it again (store_blocked)
                     dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+                } else if (PRIMARY && in_batch) {
+                    // no shadow ray for this light (mod.rs:218), or the octree dropped the hit: the term of node 0 reads back as black (mod.rs:99-100, 211)
+                    float* dst = slot_L + 3ull * ((size_t)li * ps.nslots + (size_t)chunk * ps.chunk + j + (uint32_t)lane);
+                    dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f;
                 }
             }
             // ---- reflection rays, mod.rs:146-158 + 178-196
+#ifdef MI355RT_EXP_SHADE_NOREFL
+            if (false) {
+#else
             if (level < ps.recursions) {
+#endif
                 const uint32_t k = ps.spread * (ps.recursions - level);                // num_sub_rays, mod.rs:150
                 const uint32_t index_in_level = node - ps.level_first[level];
                 // children in pairs: both first table entries are in flight before either walk starts (the walks are chains of
@@ -834,16 +863,51 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                             jx1 = __umulhi(b0, 65535u);
                         }
                         float4 tv0 = table[jx0], tv1 = table[jx1];
+#if defined(MI355RT_EXP_DIRCOH) && MI355RT_EXP_DIRCOH == 1      // timing experiment (wrong picture): every reflection ray of a chunk starts its table walk at the same entry
+                        jx0 = (chunk * 2654435761u) >> 17; jx1 = jx0 + 7u; tv0 = table[jx0]; tv1 = table[jx1];
+#endif
                         hemisphere_walk(table, n, jx0, tv0);
                         if (two) hemisphere_walk(table, n, jx1, tv1);
+#if defined(MI355RT_EXP_DIRCOH) && MI355RT_EXP_DIRCOH == 2      // timing experiment (wrong picture): every reflection ray of a chunk points into ONE octant (that of the first lane's normal): what would sorting a chunk's rays by octant buy at best?
+                        {
+                            const uint32_t oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)((n.x < 0.0f ? 1u : 0u) | (n.y < 0.0f ? 2u : 0u) | (n.z < 0.0f ? 4u : 0u)));
+                            for (int w = 0; w < 2; ++w) {
+                                uint32_t& jx = w ? jx1 : jx0; float4& tv = w ? tv1 : tv0;
+                                for (uint32_t g = 0; g < 400u; ++g) {
+                                    const uint32_t o2 = (tv.x < 0.0f ? 1u : 0u) | (tv.y < 0.0f ? 2u : 0u) | (tv.z < 0.0f ? 4u : 0u);
+                                    if (o2 == oct && tv.x * n.x + tv.y * n.y + tv.z * n.z > 0.0f) break;
+                                    jx = jx + 1u == kSampleMax ? 0u : jx + 1u; tv = table[jx];
+                                }
+                                if (!(tv.x * n.x + tv.y * n.y + tv.z * n.z > 0.0f)) hemisphere_walk(table, n, jx, tv);
+                            }
+                        }
+#endif
                         bd0 = mk3(tv0.x, tv0.y, tv0.z); bo0 = add3(hp, sscale(0.00001f, bd0));   // mod.rs:192-193
                         bd1 = mk3(tv1.x, tv1.y, tv1.z); bo1 = add3(hp, sscale(0.00001f, bd1));
+                    }
+                    // Where the batch's reflection rays go in the chunk's region: grouped by the OCTANT of their direction.  The rays of a batch start at
+                    // neighbouring hit points; those that also agree in the signs of their direction make the same near / far choice at every node, so they
+                    // walk the tree together for longer, and lanes of a quad that fetch the same node cost the memory pipe one access instead of four
+                    // (profiles/r03_notes.md: all rays of a chunk in one octant would take 14 % off the secondary trace launches).  Eight ballots per child;
+                    // the order of the records inside a region means nothing to anyone else.
+                    uint32_t pos[2] = { 0u, 0u };
+                    if (kSortBins != 0u) {
+                        const uint32_t key0 = active ? dir_bin(bd0) : kSortBins, key1 = (active && two) ? dir_bin(bd1) : kSortBins;
+                        uint32_t run = out_front;
+                        for (uint32_t b = 0; b < kSortBins; ++b) {
+                            const unsigned long long m0 = __ballot(key0 == b), m1 = __ballot(key1 == b);
+                            if (key0 == b) pos[0] = run + (uint32_t)__popcll(m0 & lanemask_lt());
+                            run += (uint32_t)__popcll(m0);
+                            if (key1 == b) pos[1] = run + (uint32_t)__popcll(m1 & lanemask_lt());
+                            run += (uint32_t)__popcll(m1);
+                        }
+                        out_front = run;
                     }
                     for (uint32_t w = 0; w < (two ? 2u : 1u); ++w) {
                         const f3 bo = w ? bo1 : bo0, bd = w ? bd1 : bd0;
                         const uint32_t child_node = w ? child1 : child0;
                         uint32_t n_new;
-                        const uint32_t oi = wave_append(active, out_front, n_new);
+                        const uint32_t oi = kSortBins != 0u ? pos[w] : wave_append(active, out_front, n_new);
                         if (active && oi + out_back < ps.region + 0u) {
                             const size_t r = base + oi;
                             st4<2>(&out_q[r], make_float4(bo.x, bo.y, bo.z, bd.x));
