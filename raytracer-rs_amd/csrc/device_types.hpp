@@ -57,7 +57,12 @@ struct DCamera {
     // chunks whose pixel footprint lies outside cannot hit anything and are skipped (cull_valid == 0: off)
     uint32_t cull_valid;      // number of rectangles below (0: culling off)
     float cull_rect[kCullRects][4];   // x0, x1, y0, y1 of the top BVH subtrees
+    // second stage (round 3): a kCullGrid x kCullGrid bit mask over the bounding rectangle of those rectangles — a cell's bit is set iff the (padded)
+    // screen rectangle of some triangle touches it.  A chunk whose footprint touches no set cell cannot hit anything.  null: first stage only.
+    const uint32_t* cull_mask;
+    float mask_x0, mask_y0, mask_inv_cx, mask_inv_cy;      // cell (i, j) = floor((dir_x - mask_x0) * mask_inv_cx), floor((dir_y - mask_y0) * mask_inv_cy)
 };
+constexpr uint32_t kCullGrid = 1024;                       // cells per axis (32 words per row, 128 KiB)
 
 struct DPass {
     // primary-sample enumeration: thread i -> s = i / npix, p = i % npix,

@@ -290,11 +290,34 @@ __device__ __forceinline__ bool chunk_is_culled(const DCamera& cam, const DPass&
     const float y_lo = -cam.max_y + 2.0f * cam.max_y * ((float)va / (float)cam.height);
     const float y_hi = -cam.max_y + 2.0f * cam.max_y * (((float)vb + 1.0f) / (float)cam.height);
     const float ex = 1e-5f * cam.max_x, ey = 1e-5f * cam.max_y;
-    for (uint32_t k = 0; k < cam.cull_valid; ++k) {
+    bool all_outside = true;
+    for (uint32_t k = 0; k < cam.cull_valid && all_outside; ++k) {
         const bool outside = x_hi + ex < cam.cull_rect[k][0] || x_lo - ex > cam.cull_rect[k][1] || y_hi + ey < cam.cull_rect[k][2] || y_lo - ey > cam.cull_rect[k][3];
-        if (!outside) return false;
+        if (!outside) all_outside = false;
     }
-    return true;
+    if (all_outside) return true;
+    // second stage: the coverage mask (renderer.cpp, refresh_cull_mask).  The footprint's cells, one (row, word) pair per lane; the wave must be
+    // whole for the ballot to see every pair (every caller is in wave-uniform control flow; if not: no culling).
+    if (cam.cull_mask == nullptr || __builtin_amdgcn_read_exec() != ~0ull) return false;
+    constexpr int G = (int)kCullGrid, wpr = G / 32;
+    const float fx0 = (x_lo - ex - cam.mask_x0) * cam.mask_inv_cx, fx1 = (x_hi + ex - cam.mask_x0) * cam.mask_inv_cx;
+    const float fy0 = (y_lo - ey - cam.mask_y0) * cam.mask_inv_cy, fy1 = (y_hi + ey - cam.mask_y0) * cam.mask_inv_cy;
+    if (!(fx0 == fx0) || !(fx1 == fx1) || !(fy0 == fy0) || !(fy1 == fy1)) return false;
+    // (the host widened every rectangle by 1/100 of a cell: the f32 rounding of these indices, < 1e-4 cells, cannot lose a touched cell)
+    const int i0 = max((int)floorf(fminf(fmaxf(fx0, -4.0f), (float)G + 4.0f)), 0), i1 = min((int)floorf(fminf(fmaxf(fx1, -4.0f), (float)G + 4.0f)), G - 1);
+    const int j0 = max((int)floorf(fminf(fmaxf(fy0, -4.0f), (float)G + 4.0f)), 0), j1 = min((int)floorf(fminf(fmaxf(fy1, -4.0f), (float)G + 4.0f)), G - 1);
+    if (i1 < i0 || j1 < j0) return true;                                 // wholly outside the mask's domain: outside every rectangle of the first stage too
+    const int w0 = i0 >> 5, nw = (i1 >> 5) - w0 + 1, nrows = j1 - j0 + 1;
+    if (nw * nrows > 64) return false;                                   // an unusually large footprint: not culled
+    const int lane = lane_id();
+    uint32_t word = 0u;
+    if (lane < nw * nrows) {
+        const int row = lane / nw, wi = w0 + (lane - row * nw);
+        word = cam.cull_mask[(j0 + row) * wpr + wi];
+        const int lo = max(i0 - wi * 32, 0), hi = min(i1 - wi * 32, 31);  // bits lo .. hi of this word belong to the footprint
+        word &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
+    }
+    return __ballot(word != 0u) == 0ull;
 }
 
 // record index of ray i of a chunk: radiance rays from the front, shadow rays from the back

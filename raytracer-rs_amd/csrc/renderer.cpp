@@ -356,7 +356,65 @@ void Renderer::collect_cull_boxes()
     }
 }
 
-DCamera Renderer::device_camera() const
+// Second culling stage: the coverage mask (device_types.hpp).  Every triangle's three vertices, padded like the boxes of the first stage, are
+// projected into the camera's (dir_x, dir_y) plane; the cells their bounding rectangle touches are set.  Any primary ray that hits a triangle has
+// its (dir_x, dir_y) inside that triangle's rectangle, so a chunk footprint that touches no set cell holds only misses.  Rebuilt (and uploaded,
+// with the renderer's streams idle) only when the camera changed; scenes of more than 2 M triangles keep the first stage only.
+bool Renderer::refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin)
+{
+    c.cull_mask = nullptr; c.mask_x0 = c.mask_y0 = 0.0f; c.mask_inv_cx = c.mask_inv_cy = 0.0f;
+    if (c.cull_valid == 0 || bvh.tris.empty() || bvh.tris.size() > (2u << 20) || getenv("MI355RT_NO_CULL_MASK")) return true;
+    std::vector<float> key(c.rot, c.rot + 16);
+    key.insert(key.end(), c.origin, c.origin + 3); key.push_back(c.max_x); key.push_back(c.max_y);
+    if (key == mask_key_) {
+        if (mask_valid_) { c.cull_mask = d_cull_mask_; c.mask_x0 = mask_dom_[0]; c.mask_y0 = mask_dom_[1]; c.mask_inv_cx = mask_dom_[2]; c.mask_inv_cy = mask_dom_[3]; }
+        return true;
+    }
+    mask_key_ = key; mask_valid_ = false;
+    // domain: the bounding rectangle of the first stage's rectangles (everything outside is empty by the first stage)
+    double X0 = 1e300, X1 = -1e300, Y0 = 1e300, Y1 = -1e300;
+    for (uint32_t k = 0; k < c.cull_valid; ++k) { X0 = std::min(X0, (double)c.cull_rect[k][0]); X1 = std::max(X1, (double)c.cull_rect[k][1]); Y0 = std::min(Y0, (double)c.cull_rect[k][2]); Y1 = std::max(Y1, (double)c.cull_rect[k][3]); }
+    if (!(X1 > X0) || !(Y1 > Y0)) return true;
+    const double icx = kCullGrid / (X1 - X0), icy = kCullGrid / (Y1 - Y0);
+    constexpr uint32_t wpr = kCullGrid / 32u;
+    std::vector<uint32_t> bits((size_t)kCullGrid * wpr, 0u);
+    for (const BvhTri& t : bvh.tris) {
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int v = 0; v < 3; ++v) {
+            const double p[3] = { (double)t.v0[0] + (v == 1 ? t.e1[0] : v == 2 ? t.e2[0] : 0.0f), (double)t.v0[1] + (v == 1 ? t.e1[1] : v == 2 ? t.e2[1] : 0.0f),
+                                  (double)t.v0[2] + (v == 1 ? t.e1[2] : v == 2 ? t.e2[2] : 0.0f) };
+            for (int k = 0; k < 8; ++k) {          // the vertex's padded cube
+                double w[3];
+                for (int a = 0; a < 3; ++a) w[a] = p[a] + ((k >> a) & 1 ? pad : -pad) - c.origin[a];
+                const double vx = w[0] * inv[0][0] + w[1] * inv[1][0] + w[2] * inv[2][0];
+                const double vy = w[0] * inv[0][1] + w[1] * inv[1][1] + w[2] * inv[2][1];
+                const double vz = w[0] * inv[0][2] + w[1] * inv[1][2] + w[2] * inv[2][2];
+                if (!(vz > zmin)) return true;                          // cannot happen behind a valid first stage; no mask then
+                const double dx = vx / vz, dy = -vy / vz;
+                x0 = std::min(x0, dx); x1 = std::max(x1, dx); y0 = std::min(y0, dy); y1 = std::max(y1, dy);
+            }
+        }
+        const double mx = 1e-4 * (x1 - x0) + 1e-6, my = 1e-4 * (y1 - y0) + 1e-6;
+        // 1/100 of a cell of slack: the kernel computes its cell indices in f32 (error < 1e-4 cells for |dir| of a few units)
+        const long i0 = std::max(0L, (long)std::floor((x0 - mx - X0) * icx - 0.01)), i1 = std::min((long)kCullGrid - 1, (long)std::floor((x1 + mx - X0) * icx + 0.01));
+        const long j0 = std::max(0L, (long)std::floor((y0 - my - Y0) * icy - 0.01)), j1 = std::min((long)kCullGrid - 1, (long)std::floor((y1 + my - Y0) * icy + 0.01));
+        for (long j = j0; j <= j1; ++j) for (long i = i0; i <= i1; ++i) bits[(size_t)j * wpr + (size_t)(i >> 5)] |= 1u << (i & 31);
+    }
+    if (!bind()) return false;
+    if (!d_cull_mask_) { if (hipMalloc((void**)&d_cull_mask_, bits.size() * 4) != hipSuccess) { d_cull_mask_ = nullptr; return true; } allocs_.push_back(d_cull_mask_); }
+    // kernels of earlier calls may still read the old mask: wait for them, then replace it (camera changes are rare and clear the film anyway, main.rs:116-169)
+    (void)hipStreamSynchronize(stream_);
+    if (trace_stream_) (void)hipStreamSynchronize(trace_stream_);
+    for (Slice& sl : slices_) if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (hipMemcpy(d_cull_mask_, bits.data(), bits.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return true;
+    mask_dom_[0] = (float)X0; mask_dom_[1] = (float)Y0; mask_dom_[2] = (float)icx; mask_dom_[3] = (float)icy;
+    mask_valid_ = true;
+    c.cull_mask = d_cull_mask_; c.mask_x0 = mask_dom_[0]; c.mask_y0 = mask_dom_[1]; c.mask_inv_cx = mask_dom_[2]; c.mask_inv_cy = mask_dom_[3];
+    if (getenv("MI355RT_DEBUG_CULL")) { size_t n = 0; for (uint32_t w : bits) n += (size_t)__builtin_popcount(w); fprintf(stderr, "[mi355rt] cull mask: %zu of %u cells set, domain x [%g, %g] y [%g, %g]\n", n, kCullGrid * kCullGrid, X0, X1, Y0, Y1); }
+    return true;
+}
+
+DCamera Renderer::device_camera()
 {
     DCamera c;
     std::memcpy(c.rot, camera.rotation().e, sizeof c.rot);
@@ -369,6 +427,7 @@ DCamera Renderer::device_camera() const
     // Valid only if every corner of the box is in front of the camera; computed in double, widened.
     c.cull_valid = 0;
     std::memset(c.cull_rect, 0, sizeof c.cull_rect);
+    c.cull_mask = nullptr; c.mask_x0 = c.mask_y0 = 0.0f; c.mask_inv_cx = c.mask_inv_cy = 0.0f;
     if (!cull_boxes_.empty() && mode_ != kModeOctreeWalk && !getenv("MI355RT_NO_CULL")) {
         const float* e = c.rot;
         const double m[3][3] = { { e[0], e[1], e[2] }, { e[4], e[5], e[6] }, { e[8], e[9], e[10] } };
@@ -403,6 +462,9 @@ DCamera Renderer::device_camera() const
                 ++n;
             }
             if (front) c.cull_valid = n;         // a box behind / around the camera: no culling at all
+            // the mask pads every vertex by ten times what the BVH pads its boxes with (bvh.cpp: 2e-5 of the diagonal) — the same assumption about
+            // the triangle test's rounding that the traversal itself rests on, with a wider margin
+            if (front) (void)refresh_cull_mask(c, inv, 2e-4 * std::sqrt(diag) + 1e-7, 1e-6 * std::sqrt(diag));
             if (getenv("MI355RT_DEBUG_CULL")) { fprintf(stderr, "[mi355rt] cull rects %u front %d max_x %g\n", n, (int)front, c.max_x); for (uint32_t k = 0; k < n; ++k) fprintf(stderr, "   x [%g, %g] y [%g, %g]\n", c.cull_rect[k][0], c.cull_rect[k][1], c.cull_rect[k][2], c.cull_rect[k][3]); }
         }
     }

@@ -68,6 +68,10 @@ public:
     uint32_t nodes_per_sample = 1;
     uint32_t level_first[kMaxLevels + 1] = { 0 };
     std::vector<std::array<float, 6>> cull_boxes_;   // top BVH subtree boxes for primary-chunk culling
+    uint32_t* d_cull_mask_ = nullptr;    // kCullGrid x kCullGrid coverage bits (device_types.hpp), rebuilt when the camera changes
+    std::vector<float> mask_key_;        // the camera the mask on the device was built for (rot, origin, max_x, max_y); empty: none
+    float mask_dom_[4] = { 0, 0, 0, 0 }; // its domain: x0, y0, 1 / cell width, 1 / cell height
+    bool mask_valid_ = false;
     uint32_t oct_stats_[8] = { 0 };       // the reference's octree: nodes, inner, leaves, empty, depth, triangle refs
     double build_ms_[2] = { 0.0, 0.0 };   // build times inside create (wall): BVH (host binned SAH, or the device build), octree (SAT, host)
     bool bvh_on_device_ = false;          // MI355RT_FLAG_DEVICE_LBVH and the device build served the scene
@@ -120,7 +124,8 @@ private:
     bool fetch_counts(uint64_t primary, bool timed_call);
     bool queue_counts_copy();
     void mark_dirty_window(uint32_t first, uint32_t total);
-    DCamera device_camera() const;
+    DCamera device_camera();
+    bool refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin);
     void collect_cull_boxes();
     void build_sample_table(std::vector<float>& table4);
     template <class T> bool upload(T*& dptr, const void* src, size_t bytes);
