@@ -555,6 +555,45 @@ def test_c5_one_rank_share_at_full_size(pkg, scenes, oracle):
         assert np.array_equal(bits(q1).reshape(h, w, 3)[r0], bits(oq).reshape(h, w, 3)[r0]), r0
 
 
+@pytest.mark.parametrize("name", ["thai2", "ico2"])
+def test_chunk_culling_stages_never_change_a_frame(pkg, scenes, monkeypatch, name):
+    """The two stages of the primary-chunk culling (rectangles of the top BVH boxes; the coverage mask of the triangles' screen rectangles) only
+    ever skip samples that miss: frames with both stages, with the first only (MI355RT_NO_CULL_MASK) and with none (MI355RT_NO_CULL) are
+    bit-identical, the mask skips at least what the rectangles skip, and all of that still holds after the camera moved (the mask is rebuilt)
+    and in a 50-row frame of the drop-in entry."""
+    w, h, spp = 960, 540, 4
+    films, culled = {}, {}
+    for mode, env in (("mask", {}), ("rects", {"MI355RT_NO_CULL_MASK": "1"}), ("none", {"MI355RT_NO_CULL": "1"})):
+        for k in ("MI355RT_NO_CULL_MASK", "MI355RT_NO_CULL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rt = make(pkg, scenes, name, w, h, seed=2)
+        out = []
+        c0 = rt.render(spp)
+        out.append(rt.film.pixel_datas())
+        rt.camera.move_rel(0.1, -0.1, 0.3); rt.camera.add_y_angle(0.07); rt.camera.add_x_angle(-0.03)
+        rt.film.clear()
+        c1 = rt.render(spp)
+        out.append(rt.film.pixel_datas())
+        rt.trace_frame_additive()
+        out.append(rt.film.pixel_datas())
+        c2 = rt.last_counts()
+        films[mode] = out
+        culled[mode] = (c0.primary_culled, c1.primary_culled, c2.primary_culled)
+        assert (c0.primary, c1.primary) == (w * h * spp, w * h * spp)
+        del rt
+    for mode in ("rects", "none"):
+        for a, b in zip(films["mask"], films[mode]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), mode
+    assert culled["none"] == (0, 0, 0)
+    for i in range(3):
+        assert culled["mask"][i] >= culled["rects"][i]
+    if name == "thai2":
+        assert culled["mask"][0] > culled["rects"][0] > 0 and culled["mask"][1] > culled["rects"][1]
+
+
 def _random_scene(scenes, ntri, seed):
     """ntri small random triangles in a slab in front of the 4boxes camera (materials / light from 4boxes)."""
     rng = np.random.default_rng(seed)
