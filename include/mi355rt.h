@@ -142,6 +142,8 @@ typedef struct mi355rt_ray_counts {
     uint64_t trace_secondary_launches;
     double shader_clock_mhz; /* only with MI355RT_FLAG_COUNT_STEPS: the clock the trace waves actually ran at, sum of delta s_memtime over
                               * sum of delta s_memrealtime (100 MHz) of all waves of the call's trace launches; 0 when not measured */
+    uint64_t shadow_skipped; /* shadow rays (counted in `shadow`) never traced: the depth cube map around their light proves that nothing lies
+                              * between the shaded point and the light, so no intersector could block them; traced shadow rays = shadow - shadow_skipped */
 } mi355rt_ray_counts;
 
 void mi355rt_default_config(mi355rt_config* cfg);
@@ -244,6 +246,12 @@ int mi355rt_debug_numerics(mi355rt_handle* h, const float* a, const float* b, si
  * reference's own known-answer vectors (oct_tree_intersector.rs:475-512) run through the HIP path. */
 int mi355rt_debug_slab(mi355rt_handle* h, const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
+/* The depth cube map the library builds around a point light (csrc/lightmap.hpp; what lets the shade kernels leave out the shadow rays of
+ * mod.rs:224-232 whose way to the light is provably free).  HOST code, no device needed: out_dist2[6 * res * res] receives, per direction texel
+ * (face = 2 * major axis + (component negative), then i over the lower and j over the higher of the two other axes), a lower bound of the squared
+ * distance from `light` to any of the ntri triangles (tri_verts: ntri x 9 floats) padded by `pad`, +inf where no triangle is seen; *nearest the
+ * distance to the nearest triangle.  Exists so that the bound can be checked against brute force without a GPU. */
+int mi355rt_debug_light_map(const float* tri_verts, uint32_t ntri, const float light[3], double pad, uint32_t res, float* out_dist2, double* nearest);
 
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,
  * [4] node bytes, [5] triangle bytes, [6] BVH build time inside create (wall, microseconds; host SAH build, or the device

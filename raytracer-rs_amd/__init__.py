@@ -80,12 +80,13 @@ class RayCounts(C.Structure):
         ("inner_execs", C.c_uint64), ("leaf_execs", C.c_uint64),
         ("trace_ms", C.c_double), ("total_ms", C.c_double),
         ("trace_secondary_ms", C.c_double), ("trace_secondary_launches", C.c_uint64), ("shader_clock_mhz", C.c_double),
+        ("shadow_skipped", C.c_uint64),
     ]
 
     def as_dict(self):
         d = {name: getattr(self, name) for name, _ in self._fields_}
         d["total_rays"] = self.primary + self.bounce + self.shadow
-        d["traced_rays"] = d["total_rays"] - self.primary_culled
+        d["traced_rays"] = d["total_rays"] - self.primary_culled - self.shadow_skipped
         return d
 
 
@@ -130,6 +131,7 @@ ABI = [
     ("mi355rt_debug_numerics", C.c_int, [_H, _F, _F, C.c_size_t, _F, _F, _F]),
     ("mi355rt_debug_slab", C.c_int, [_H, _F, _F, C.c_size_t, C.POINTER(C.c_uint8), _F]),
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
+    ("mi355rt_debug_light_map", C.c_int, [_F, C.c_uint32, _F, C.c_double, C.c_uint32, _F, C.POINTER(C.c_double)]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
     ("mi355rt_octree_stats", C.c_int, [_H, _U]),
     ("mi355rt_bvh_build_info", C.c_int, [_H, _U]),
@@ -509,6 +511,17 @@ def create_raytracer_from_arrays(scene, triangles_per_leaf, width, height, **cfg
     h = C.c_void_p()
     code = lib().mi355rt_create(C.byref(sd), C.byref(cfg), C.byref(h))
     return _finish(code, h, keep)
+
+
+def debug_light_map(tri_verts, light, pad, res):
+    """(dist2[6, res, res], nearest): the depth cube map the library builds around a point light (host code; include/mi355rt.h)"""
+    v = np.ascontiguousarray(tri_verts, np.float32).reshape(-1, 9)
+    l = np.ascontiguousarray(light, np.float32).reshape(3)
+    out = np.zeros((6, res, res), np.float32); nearest = C.c_double(0.0)
+    code = lib().mi355rt_debug_light_map(_fp(v), v.shape[0], _fp(l), float(pad), int(res), _fp(out), C.byref(nearest))
+    if code != 0:
+        raise RuntimeError("mi355rt_debug_light_map failed: %d" % code)
+    return out, nearest.value
 
 
 def comm_unique_id():

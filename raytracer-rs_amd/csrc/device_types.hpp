@@ -24,7 +24,9 @@ constexpr uint32_t kShadeCursorOffset = 128;                   // the shade laun
 constexpr uint32_t kConfirmCursorOffset = 64;                  // the confirm launch of a round: its cursors sit 256 B after the trace launch's
 
 struct DMaterial { float r, g, b; uint32_t kind_tex; };       // kind_tex: bit 31 = texture, low bits = texture id
-struct DLight { float px, py, pz, cr, cg, cb; };
+struct DLight { float px, py, pz, cr, cg, cb;
+                float tail2;   // (distance to the nearest triangle, padded)^2: a shadow ray runs 1 % of its length PAST the light (t in (0.99, 1)); nothing is there while 1e-4 |l|^2 < tail2
+                float pad; };
 struct DTexture { uint32_t width, height; uint64_t offset; }; // offset in texels into the texel pool
 
 struct DScene {
@@ -41,6 +43,8 @@ struct DScene {
     const void* prim_tris;    // BvhTri[] in ORIGINAL triangle order (reference-exact intersector only)
     const int2* oct_info;     // per octree node, what the confirm walk needs in ONE 8-byte load: x = first child (>= 0) or ~tri_first (leaf), y = leaf triangle count
     const uint32_t* tri_home; // per triangle: the one octree leaf that lists it, or 0xFFFFFFFF when several do
+    const float* light_maps;  // per light a depth cube map [6][res][res]: lower bound of the squared distance from the light to anything seen in the texel's directions (lightmap.hpp); null: none
+    uint32_t light_map_res;   // texels per face edge (0: no maps)
     int32_t root;
     uint32_t nlights;
     uint32_t ntri;
@@ -105,6 +109,7 @@ struct DCounters {            // one set per render call, zeroed at its start
     unsigned int overflow;
     unsigned int pad;
     unsigned long long primary_culled;            // primary samples in chunks the frustum culling skipped (never traced)
+    unsigned long long shadow_skipped;            // shadow rays the light's depth map proved unoccluded (never traced; counted in `shadow` by the host)
     unsigned long long t_first_end, t_last_end, t_sum_end, t_start, n_waves;   // COUNT mode: wave end times (s_memrealtime ticks, 100 MHz)
     unsigned long long lanes_inner, lanes_leaf, lanes_done, lane_samples;   // COUNT mode: where the lanes are at every loop iteration (summed lane counts; samples = iterations)
     unsigned long long t_sum_cycles, t_sum_real;                                            // COUNT mode: summed s_memtime ticks (shader cycles) of the waves, against t_sum_end in s_memrealtime ticks

@@ -69,7 +69,7 @@ bool DeviceGroup::render(uint32_t spp, bool wait)
     for (size_t i = 0; i < devs_.size(); ++i) {
         if (!ok[i]) return fail_from(i);
         const mi355rt_ray_counts& c = devs_[i]->counts;
-        counts_.primary += c.primary; counts_.bounce += c.bounce; counts_.shadow += c.shadow; counts_.primary_hits += c.primary_hits;
+        counts_.primary += c.primary; counts_.bounce += c.bounce; counts_.shadow += c.shadow; counts_.shadow_skipped += c.shadow_skipped; counts_.primary_hits += c.primary_hits;
         counts_.primary_culled += c.primary_culled; counts_.nodes_visited += c.nodes_visited; counts_.tris_tested += c.tris_tested;
         counts_.trace_launches += c.trace_launches; counts_.inner_execs += c.inner_execs; counts_.leaf_execs += c.leaf_execs;
         counts_.trace_ms += c.trace_ms; counts_.total_ms = std::max(counts_.total_ms, c.total_ms);
@@ -88,7 +88,7 @@ bool DeviceGroup::last_counts(mi355rt_ray_counts& out)
     for (size_t i = 0; i < devs_.size(); ++i) {
         mi355rt_ray_counts c{};
         if (!devs_[i]->last_counts(c)) return fail_from(i);
-        out.primary += c.primary; out.bounce += c.bounce; out.shadow += c.shadow; out.primary_hits += c.primary_hits;
+        out.primary += c.primary; out.bounce += c.bounce; out.shadow += c.shadow; out.shadow_skipped += c.shadow_skipped; out.primary_hits += c.primary_hits;
         out.primary_culled += c.primary_culled; out.nodes_visited += c.nodes_visited; out.tris_tested += c.tris_tested;
         out.trace_launches += c.trace_launches; out.inner_execs += c.inner_execs; out.leaf_execs += c.leaf_execs;
         out.trace_ms += c.trace_ms; out.total_ms = std::max(out.total_ms, c.total_ms);

@@ -731,6 +731,32 @@ __device__ __forceinline__ uint32_t dir_bin(const f3 d)
     return oct * 3u + major;
 }
 
+// Is the way from the shaded point to light li provably free?  l = light - hp (mod.rs:215).  The shadow ray of mod.rs:224-225 starts at hp + 0.01 l and
+// is searched on t in [0, 1): from 0.99 |l| in front of the light, through it, to 0.01 |l| behind it — every point of it in the direction -l (or +l)
+// from the light.  The light's depth cube map (lightmap.hpp) bounds from below the squared distance to anything seen in the texel of -l, the
+// light's tail2 the distance to anything at all: with both bounds beyond the ray's reach no triangle can be hit, so the ray is not blocked whatever
+// intersector answers (mod.rs:226-232) and it need not be traced.  Conservative like the BVH's boxes: the maps are padded (renderer.cpp).
+__device__ __forceinline__ bool light_proves_unoccluded(const DScene& sc, uint32_t li, const DLight& lt, const f3 l)
+{
+    const uint32_t R = sc.light_map_res;
+    if (R == 0u) return false;
+    const float l2 = l.x * l.x + l.y * l.y + l.z * l.z;
+    const float vx = -l.x, vy = -l.y, vz = -l.z;                      // from the light to the shaded point
+    const float ax = fabsf(vx), ay = fabsf(vy), az = fabsf(vz);
+    uint32_t m; float vm, va, vb;                                       // major axis, the two others in ascending order (lightmap.cpp)
+    if (ax >= ay && ax >= az) { m = 0u; vm = vx; va = vy; vb = vz; }
+    else if (ay >= az) { m = 1u; vm = vy; va = vx; vb = vz; }
+    else { m = 2u; vm = vz; va = vx; vb = vy; }
+    const float am = fabsf(vm);
+    if (!(am > 0.0f) || !(l2 < 3.0e38f)) return false;
+    const float fR = (float)R, u = div_rn(va, am), v = div_rn(vb, am);
+    const int i = min(max((int)((u * 0.5f + 0.5f) * fR), 0), (int)R - 1), j = min(max((int)((v * 0.5f + 0.5f) * fR), 0), (int)R - 1);
+    const uint32_t face = 2u * m + (vm < 0.0f ? 1u : 0u);
+    const float bound = sc.light_maps[((size_t)(li * 6u + face) * R + (uint32_t)i) * R + (uint32_t)j];
+    // 0.98011 > 0.99^2 and 1.0002e-4 > 0.01^2: the rounding of l2 and of the ray's origin (1e-7) stays inside
+    return (l2 * 0.98011f < bound) & (l2 * 1.0002e-4f < lt.tail2);
+}
+
 // ---- shade: hit records -> light terms, shadow rays and reflection rays -----------------------------
 // Shade the hits of one chunk (one wave): see the header of this file.
 // in_nrad: radiance rays of the chunk in in_q (ignored for PRIMARY); out_nrad / out_nshadow: what was appended to out_q.
@@ -787,7 +813,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             }
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t out_front = 0u, out_back = 0u, dropped = 0u;
+        uint32_t out_front = 0u, out_back = 0u, dropped = 0u, skipped = 0u;
         for (uint32_t j = 0; j < cnt; j += 64u) {
             bool active = j + (uint32_t)lane < cnt;
             const bool in_batch = active;                      // PRIMARY: owns the light-term slot chunk * ps.chunk + j + lane, shaded or not
@@ -826,7 +852,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             }
             // ---- shade() set-up per light, mod.rs:214-257; the shadow ray carries the finished term
             for (uint32_t li = 0; li < sc.nlights; ++li) {
-                bool want = false;
+                bool want = false, is_free = false;
                 f3 c = mk3(0, 0, 0);
                 if (active) {
                     const DLight lt = sc.lights[li];
@@ -835,6 +861,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
                     const float ndl = dot3(n, ln);                                     // mod.rs:216
                     if (!(ndl < 0.0f)) {                                               // mod.rs:218
                         want = true;                                                   // the shadow ray of mod.rs:224-225: rebuilt from hp by its tracer (shadow_ray_of)
+                        is_free = light_proves_unoccluded(sc, li, lt, l);
                         const DMaterial m = sc.materials[geom];
                         f3 diffuse = mk3(m.r, m.g, m.b);
                         if (m.kind_tex & 0x80000000u) diffuse = fetch_texel(sc, m.kind_tex & 0x7FFFFFFFu, h.y, h.z);
@@ -848,11 +875,13 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
 #ifdef MI355RT_EXP_SHADE_NOLIGHT
                 want = false;
 #endif
-                const uint32_t oi = wave_append(want, out_back, n_new);
-                if (want && out_front + oi < ps.region) {
-                    const size_t r = base + (ps.region - 1u - oi);
+                // a shadow ray the light's depth map proves free is never made: its term stands as written
+                const bool ray = want && !is_free;
+                skipped += (uint32_t)__popcll(__ballot(want && is_free));
+                const uint32_t oi = wave_append(ray, out_back, n_new);
+                if (want && (!ray || out_front + oi < ps.region)) {
                     const uint32_t term = 3u * ((node * sc.nlights + li) * ps.nslots + slot);             // float index in slot_L (< 2^32: renderer.cpp)
-                    st4<2>(&out_q[r], make_float4(hp.x, hp.y, hp.z, __uint_as_float(term)));
+                    if (ray) st4<2>(&out_q[base + (ps.region - 1u - oi)], make_float4(hp.x, hp.y, hp.z, __uint_as_float(term)));
                     float* dst = slot_L + term;                    // optimistic: whoever finds the shadow ray blocked zeroes it again (store_blocked)
                     dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
                 } else if (PRIMARY && in_batch) {
@@ -944,7 +973,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
         if (out_front + out_back > ps.region) { if (lane == 0) counters->overflow = 1u; out_front = 0u; out_back = 0u; }
         if (out_counts != nullptr && lane == 0) out_counts[chunk] = make_uint2(out_front, out_back);     // fused launch: null, the counts travel in registers
         out_nrad = out_front; out_nshadow = out_back;
-        acc_bounce += out_front; acc_shadow += out_back; acc_hits += cnt - dropped;
+        acc_bounce += out_front; acc_shadow += out_back + ((unsigned long long)skipped << 32); acc_hits += cnt - dropped;     // high half of acc_shadow: shadow rays never made
     }
 }
 
@@ -953,7 +982,8 @@ __device__ __forceinline__ void flush_shade_counters(DCounters* counters, uint32
     if (lane_id() == 0) {
         DCounters* cs = &counters[wave % kShards];
         if (acc_bounce) atomicAdd(&cs->bounce, acc_bounce);
-        if (acc_shadow) atomicAdd(&cs->shadow, acc_shadow);
+        if (acc_shadow & 0xFFFFFFFFull) atomicAdd(&cs->shadow, acc_shadow & 0xFFFFFFFFull);
+        if (acc_shadow >> 32) atomicAdd(&cs->shadow_skipped, acc_shadow >> 32);
         if (acc_hits & 0xFFFFFFFFull) atomicAdd(&cs->primary_hits, acc_hits & 0xFFFFFFFFull);
         if (acc_hits >> 32) atomicAdd(&cs->primary_culled, acc_hits >> 32);
     }

@@ -1,5 +1,6 @@
 // renderer.cpp — see renderer.hpp.
 #include "renderer.hpp"
+#include "lightmap.hpp"
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -183,7 +184,40 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     std::vector<DLight> lights(std::max<size_t>(scene.lights.size(), 1));
     for (size_t i = 0; i < scene.lights.size(); ++i) {
         const LightData& l = scene.lights[i];
-        lights[i] = DLight{ l.pos[0], l.pos[1], l.pos[2], l.color[0], l.color[1], l.color[2] };
+        lights[i] = DLight{ l.pos[0], l.pos[1], l.pos[2], l.color[0], l.color[1], l.color[2], 0.0f, 0.0f };
+    }
+    // Depth cube maps around the lights (lightmap.hpp): shadow rays they prove free are never made.  Resolution: 512 texels per face edge, halved
+    // until the build stays under ~4 M texel updates (a scene of a few huge triangles) and the maps under 64 MiB; padded by ten times the BVH's
+    // own padding (bvh.cpp: 2e-5 of the scene diagonal), the margin the culling mask uses.
+    float* d_light_maps = nullptr; uint32_t light_map_res = 0;
+    if (!scene.lights.empty() && scene.lights.size() <= 8 && ntri > 0 && !getenv("MI355RT_NO_LIGHT_MAP")) {
+        const auto t_lm = std::chrono::steady_clock::now();
+        double diag2 = 0.0;
+        { float mn[3] = { 3e38f, 3e38f, 3e38f }, mx[3] = { -3e38f, -3e38f, -3e38f };
+          for (size_t i = 0; i < scene.tri_verts.size(); ++i) { const int a = (int)(i % 3); mn[a] = std::min(mn[a], scene.tri_verts[i]); mx[a] = std::max(mx[a], scene.tri_verts[i]); }
+          for (int a = 0; a < 3; ++a) diag2 += ((double)mx[a] - mn[a]) * ((double)mx[a] - mn[a]); }
+        const double pad = 2e-4 * std::sqrt(diag2) + 1e-7;
+        uint32_t res = 512;
+        if (const char* e = getenv("MI355RT_LIGHT_MAP_RES")) { int v = atoi(e); if (v >= 16 && v <= 2048) res = (uint32_t)v; }
+        while (res > 16 && (size_t)6 * res * res * 4 * scene.lights.size() > ((size_t)64 << 20)) res /= 2;
+        for (const LightData& l : scene.lights) while (res > 16 && light_map_work(scene.tri_verts.data(), ntri, l.pos, res) > (4ull << 20)) res /= 2;
+        std::vector<float> all; all.reserve((size_t)6 * res * res * scene.lights.size());
+        bool finite = true;
+        for (size_t i = 0; i < scene.lights.size() && finite; ++i) {
+            const LightData& l = scene.lights[i];
+            if (!std::isfinite(l.pos[0]) || !std::isfinite(l.pos[1]) || !std::isfinite(l.pos[2])) { finite = false; break; }
+            LightMap lm; build_light_map(scene.tri_verts.data(), ntri, l.pos, pad, res, lm);
+            all.insert(all.end(), lm.dist2.begin(), lm.dist2.end());
+            const double tail = std::max(lm.nearest - pad, 0.0);
+            lights[i].tail2 = std::isfinite(tail) ? (float)std::min(tail * tail * (1.0 - 1e-6), 3.0e38) : 3.0e38f;
+            if ((double)lights[i].tail2 > tail * tail) lights[i].tail2 = std::nextafterf(lights[i].tail2, 0.0f);
+        }
+        if (finite) {
+            if (!upload(d_light_maps, all.data(), all.size() * sizeof(float))) return bail();
+            light_map_res = res;
+        }
+        light_map_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lm).count();
+        if (getenv("MI355RT_DEBUG_CULL")) fprintf(stderr, "[mi355rt] light maps: %zu lights, %u texels per face edge, %.1f ms\n", scene.lights.size(), light_map_res, light_map_ms_);
     }
     if (!upload(d_lights, lights.data(), lights.size() * sizeof(DLight))) return bail();
     std::vector<DTexture> tex(std::max<size_t>(scene.textures.size(), 1));
@@ -199,6 +233,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     dscene_.nodes = d_nodes; dscene_.tris = d_tris; dscene_.normals = d_normals; dscene_.materials = d_mats;
     dscene_.lights = d_lights; dscene_.textures = d_tex; dscene_.texels = d_texels; dscene_.table = d_table;
     dscene_.root = bvh.root; dscene_.nlights = nlights_; dscene_.ntri = ntri;
+    dscene_.light_maps = d_light_maps; dscene_.light_map_res = light_map_res;
     dscene_.oct_nodes = nullptr; dscene_.oct_leaf_tris = nullptr; dscene_.prim_tris = nullptr; dscene_.oct_info = nullptr; dscene_.tri_home = nullptr; dscene_.oct_single_leaf = 0u;
     std::memset(dscene_.oct_root, 0, sizeof dscene_.oct_root);
     // Intersector semantics.  Default: the reference's default intersector (OctTreeIntersector), served by
@@ -723,12 +758,13 @@ bool Renderer::fetch_counts(uint64_t primary, bool timed_call)
         const DCounters& s = shard[i];
         c.bounce += s.bounce; c.shadow += s.shadow; c.primary_hits += s.primary_hits;
         c.nodes_visited += s.nodes_visited; c.tris_tested += s.tris_tested; c.overflow |= s.overflow;
-        c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs; c.primary_culled += s.primary_culled;
+        c.inner_execs += s.inner_execs; c.leaf_execs += s.leaf_execs; c.primary_culled += s.primary_culled; c.shadow_skipped += s.shadow_skipped;
         c.t_sum_cycles += s.t_sum_cycles; c.t_sum_real += s.t_sum_real;
         for (int k = 0; k < 6; ++k) c.visits_below[k] += s.visits_below[k];
     }
     counts = mi355rt_ray_counts{};
-    counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow; counts.primary_hits = c.primary_hits;
+    counts.primary = primary; counts.bounce = c.bounce; counts.shadow = c.shadow + c.shadow_skipped; counts.primary_hits = c.primary_hits;
+    counts.shadow_skipped = c.shadow_skipped;     // shadow rays of mod.rs:226 that were never made: the light's depth map proved them free
     counts.nodes_visited = c.nodes_visited; counts.tris_tested = c.tris_tested; counts.trace_launches = launches_;
     counts.inner_execs = c.inner_execs; counts.leaf_execs = c.leaf_execs; counts.primary_culled = c.primary_culled;
     if (getenv("MI355RT_DEBUG_UTIL") && c.nodes_visited)

@@ -74,6 +74,7 @@ public:
     bool mask_valid_ = false;
     uint32_t oct_stats_[8] = { 0 };       // the reference's octree: nodes, inner, leaves, empty, depth, triangle refs
     double build_ms_[2] = { 0.0, 0.0 };   // build times inside create (wall): BVH (host binned SAH, or the device build), octree (SAT, host)
+    double light_map_ms_ = 0.0;           // build time of the lights' depth cube maps inside create
     bool bvh_on_device_ = false;          // MI355RT_FLAG_DEVICE_LBVH and the device build served the scene
     double lbvh_device_ms_ = 0.0;         // its device time (kernels + sort)
     enum Mode { kModeConfirm = 0, kModeOctreeWalk = 1, kModeTrueClosest = 2 };

@@ -594,6 +594,46 @@ def test_chunk_culling_stages_never_change_a_frame(pkg, scenes, monkeypatch, nam
         assert culled["mask"][0] > culled["rects"][0] > 0 and culled["mask"][1] > culled["rects"][1]
 
 
+@pytest.mark.parametrize("name,light", [("thai2", None), ("thai2", (0.0, 0.0, 6.0)), ("thai2", (-1.5, -2.0, 3.0)), ("ico2", None), ("ico2", (0.05, 0.02, 0.01)),
+                                        ("4boxes", None), ("4boxes", (1.0, 0.4, 1.0)), ("ico3_tex", (30.0, 40.0, -25.0))])
+def test_light_depth_maps_never_change_a_frame(pkg, scenes, oracle, sem3, monkeypatch, name, light):
+    """Shadow rays that the depth cube map around their light proves free are never made (shadow_skipped).  With the file's light, with lights
+    in the middle of the geometry (the ray's 1 % tail behind the light matters there), inside a mesh, and far outside: film, pixels and every
+    counter equal the run without maps (MI355RT_NO_LIGHT_MAP) bit for bit in all three intersector semantics, a second, re-coloured light
+    included; and the default semantics equal the oracle."""
+    sc = dict(scenes(name))
+    if light is not None:
+        sc["lights"] = sc["lights"].copy(); sc["lights"][0, :3] = light
+    second = sc["lights"][0].copy(); second[:3] = second[:3][::-1] * np.float32(0.7); second[3:] = [0.5, 2.0, 1.0]
+    sc["lights"] = np.concatenate([sc["lights"][:1], second[None, :]]).astype(np.float32)
+    w, h, spp = 160, 120, 3
+    runs = {}
+    for mode in ("maps", "none"):
+        monkeypatch.delenv("MI355RT_NO_LIGHT_MAP", raising=False)
+        if mode == "none":
+            monkeypatch.setenv("MI355RT_NO_LIGHT_MAP", "1")
+        rt = pkg.create_raytracer_from_arrays(sc, 70, w, h, seed=4, flags=sem3.gpu)
+        c = rt.render(spp)
+        rt.camera.move_rel(0.2, 0.1, -0.3); rt.camera.add_y_angle(-0.05)
+        for _ in range(3):
+            rt.trace_frame_additive()
+        c2 = rt.last_counts()
+        runs[mode] = (rt.film.pixel_datas(), rt.get_tonemapped_pixels(), (c.primary, c.bounce, c.shadow, c.primary_hits), (c2.bounce, c2.shadow), c.shadow_skipped + c2.shadow_skipped)
+        del rt
+    (fa, pa, ca, c2a, skipped), (fb, pb, cb, c2b, none_skipped) = runs["maps"], runs["none"]
+    assert ca == cb and c2a == c2b and none_skipped == 0
+    assert np.array_equal(pa, pb)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert 0 <= skipped <= ca[2] + c2a[1]
+    if light is None or name == "ico3_tex":
+        assert skipped > 0                                     # an outside light: most lit points are proved free
+    if sem3.orc is not None and name != "thai2":
+        orc = oracle.Oracle(sc, w, h, seed=4, flags=sem3.orc)
+        oc = orc.render(spp, nthreads=8)
+        assert ca == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
+
+
 def _random_scene(scenes, ntri, seed):
     """ntri small random triangles in a slab in front of the 4boxes camera (materials / light from 4boxes)."""
     rng = np.random.default_rng(seed)

@@ -32,7 +32,7 @@ for combo in itertools.product(*sweeps) if sweeps else [()]:
         out.append("N=%d share: min %.3f med %.3f ms (gpu %.3f; %.1f GB HBM)" % (world, ts[0] * 1e3, ts[len(ts) // 2] * 1e3, c.total_ms, rt.hbm_allocated_bytes() / 1e9))
         if os.environ.get("SWEEP_COUNT"):          # nodes visited / triangles tested per ray (instrumented frame, 4 spp)
             rt.set_flags(pkg.FLAG_COUNT_STEPS); rt.film.clear(); cc = rt.render(4); rt.set_flags(0)
-            rays = cc.primary - cc.primary_culled + cc.bounce + cc.shadow
+            rays = cc.primary - cc.primary_culled + cc.bounce + cc.shadow - cc.shadow_skipped
             st = rt.accel_stats()
             out[-1] += " [%.2f nodes %.2f tris per traced ray; %d nodes depth %d build %.1f ms]" % (cc.nodes_visited / rays, cc.tris_tested / rays, st["nodes"], st["max_depth"], st["bvh_build_ms"])
         del rt
