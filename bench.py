@@ -322,10 +322,10 @@ class FrameSetup:
         self.sync()
         elapsed = time.perf_counter() - t0
         c = self.rt.last_counts()
-        same = (c.primary, c.bounce, c.shadow, c.primary_culled) == (ref.primary, ref.bounce, ref.shadow, ref.primary_culled)
+        same = (c.primary, c.bounce, c.shadow, c.primary_culled, c.shadow_skipped) == (ref.primary, ref.bounce, ref.shadow, ref.primary_culled, ref.shadow_skipped)
         if not same:
             raise SystemExit("bench: a queued frame traced other rays than the synchronous one: %s vs %s" % (c.as_dict(), ref.as_dict()))
-        tot = [float(steps * c.primary), float(steps * c.bounce), float(steps * c.shadow), float(steps * c.primary_culled)]
+        tot = [float(steps * c.primary), float(steps * c.bounce), float(steps * c.shadow), float(steps * c.primary_culled), float(steps * c.shadow_skipped)]
         for _ in range(2):                                              # the gather timed on its own (render excluded)
             self.step(time_gather=True)
         self.sync()
@@ -340,11 +340,11 @@ class FrameSetup:
         return elapsed, vals, step_ms
 
     def summary(self, workload, scaling, steps, warmup, elapsed, vals):
-        primary, bounce, shadow, culled = vals
+        primary, bounce, shadow, culled, skipped = vals
         total = primary + bounce + shadow
         return {"workload": workload, "scaling": scaling, "steps": steps, "warmup": warmup,
                 "ms_per_step": round(elapsed / steps * 1e3, 3), "value": round(total / elapsed / 1e6, 2), "unit": "Mrays/s",
-                "traced_mrays_per_s": round((total - culled) / elapsed / 1e6, 2),
+                "traced_mrays_per_s": round((total - culled - skipped) / elapsed / 1e6, 2),
                 "gather_ms_rank0": round(sorted(self.gather_ms)[len(self.gather_ms) // 2], 3) if self.gather_ms else None,
                 "gather_path": self.gather_path, "rccl_ranks": self.rccl_ranks, "gather_error": self.gather_error,
                 "slices": self.slices, "hbm_allocated_bytes_rank0": self.rt.hbm_allocated_bytes()}
@@ -457,7 +457,7 @@ def main(argv=None):
     rt.set_flags(base_flags | pkg.FLAG_COUNT_STEPS)
     rt.film.clear()
     c = rt.render(max(1, min(4, spp)))
-    inst_rays = max(1, c.primary + c.bounce + c.shadow)
+    inst_rays = max(1, c.primary - c.primary_culled + c.bounce + c.shadow - c.shadow_skipped)       # traced rays
     nodes_per_ray = c.nodes_visited / inst_rays
     tris_per_ray = c.tris_tested / inst_rays
     lane_inner = c.nodes_visited / (64.0 * c.inner_execs) if c.inner_execs else None
@@ -466,7 +466,7 @@ def main(argv=None):
     rt.set_flags(base_flags)
 
     elapsed, vals, step_ms = fs.timed(args.steps, args.warmup)
-    primary, bounce, shadow, culled = vals
+    primary, bounce, shadow, culled, skipped = vals
     total_rays = primary + bounce + shadow
 
     # Kernel-timing loop for the roofline: the same frames again with ONE slice and HIP events around every
@@ -481,7 +481,7 @@ def main(argv=None):
     k = dict(rays=0, sec_rays=0, trace_ms=0.0, sec_ms=0.0, launches=0, sec_launches=0)
     for _ in range(ksteps):
         c = fs.step()
-        k["rays"] += c.primary + c.bounce + c.shadow; k["sec_rays"] += c.bounce + c.shadow
+        k["rays"] += c.primary - c.primary_culled + c.bounce + c.shadow - c.shadow_skipped; k["sec_rays"] += c.bounce + c.shadow - c.shadow_skipped      # rays the launches actually trace
         k["trace_ms"] += c.trace_ms; k["sec_ms"] += c.trace_secondary_ms
         k["launches"] += c.trace_launches; k["sec_launches"] += c.trace_secondary_launches
     fs.sync()
@@ -556,7 +556,7 @@ def main(argv=None):
                           "concurrent slices whose kernels overlap" % (ksteps, serial_ms_per_step, slices),
                 "pmc": {"source": "rocprofv3 --pmc child passes of this same run (bench.py --pmc-child: %d frames, 1 slice), secondary trace launches; counters are used PER RAY "
                                   "(same frame, same seed, same passes as the timed process)" % PMC_CHILD_FRAMES, "note": pmc_note}}
-        child_sec_rays = (bounce + shadow) / max(args.steps * world, 1) * PMC_CHILD_FRAMES       # secondary rays the child's frames trace (same frame, same seed)
+        child_sec_rays = (bounce + shadow - skipped) / max(args.steps * world, 1) * PMC_CHILD_FRAMES       # secondary rays the child's frames trace (same frame, same seed)
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc and child_sec_rays > 0:
             acc_per_ray = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"][0] / child_sec_rays
             roof["pmc"]["cache_line_accesses_per_secondary_ray"] = round(acc_per_ray, 2)
@@ -621,9 +621,10 @@ def main(argv=None):
             "hbm_allocated_bytes": main_group["hbm_allocated_bytes_rank0"],
             "primary_mrays_per_s": round(primary / elapsed / 1e6, 2),
             "traced_mrays_per_s": main_group["traced_mrays_per_s"],
-            "traced_note": "value counts every primary sample (the reference's stats.rs:27 definition); traced_mrays_per_s leaves out the primary "
-                           "samples of chunks the frustum culling skipped without tracing (%.1f %% of the primary samples)" % (100.0 * culled / max(primary, 1)),
-            "rays_per_frame": {"primary": primary / args.steps, "bounce": bounce / args.steps, "shadow": shadow / args.steps, "primary_culled": culled / args.steps},
+            "traced_note": "value counts every ray the reference casts (primary samples by its stats.rs:27 definition, reflection rays, shadow rays); traced_mrays_per_s leaves out "
+                           "the primary samples of chunks the culling skipped without tracing (%.1f %% of the primary samples) and the shadow rays the lights' depth maps proved "
+                           "free (%.1f %% of the shadow rays): work whose outcome was known" % (100.0 * culled / max(primary, 1), 100.0 * skipped / max(shadow, 1)),
+            "rays_per_frame": {"primary": primary / args.steps, "bounce": bounce / args.steps, "shadow": shadow / args.steps, "primary_culled": culled / args.steps, "shadow_skipped": skipped / args.steps},
             "other_semantics": other,
             "roofline": roof,
             "accel": dict(acc, builder=("device LBVH (MI355RT_FLAG_DEVICE_LBVH)" if build_info["on_device"] else "host binned SAH"),

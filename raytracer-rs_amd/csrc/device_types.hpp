@@ -65,6 +65,12 @@ struct DCamera {
     // screen rectangle of some triangle touches it.  A chunk whose footprint touches no set cell cannot hit anything.  null: first stage only.
     const uint32_t* cull_mask;
     float mask_x0, mask_y0, mask_inv_cx, mask_inv_cy;      // cell (i, j) = floor((dir_x - mask_x0) * mask_inv_cx), floor((dir_y - mask_y0) * mask_inv_cy)
+    // Screen-space triangle bins for the primary rays (round 3; kernels.hip, raster_kernel): the 64 samples a wave takes together are a tile of
+    // tile_cols columns x tile_rg rows; tile (row / tile_rg) * tile_nblocks + column / tile_cols lists every triangle a primary ray of the tile can
+    // hit, nearest first.  null: no bins (the primary rays walk the BVH).
+    const uint2* tile_ofs;        // per tile: x = first entry, y = number of entries
+    const uint2* tile_entries;    // x = triangle (index into DScene::tris), y = float bits of a lower bound of its distance from the camera
+    uint32_t tile_cols, tile_rg, tile_nblocks;
 };
 constexpr uint32_t kCullGrid = 1024;                       // cells per axis (32 words per row, 128 KiB)
 

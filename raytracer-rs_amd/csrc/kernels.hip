@@ -540,6 +540,79 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? MI355RT_PRIMARY_BLOCKS : 8) void 
     trace_wave<PRIMARY, COUNT, false, CONFIRM>(sc, cam, ps, in_q, in_counts, hits, cursor, slot_L, film_n, counters, &s_stack[threadIdx.x], 0u, 0u, 0u);
 }
 
+// ---- primary rays through the screen-space triangle bins (DCamera::tile_ofs; renderer.cpp, refresh_tile_bins) ----------------------------
+// The closest hit of the primary rays, found without the tree: the 64 samples a wave takes together are one tile of the image, the tile's list
+// holds every triangle a ray of the tile can hit (nearest first), and every lane tests the SAME triangle at the same time — the triangle comes
+// through the scalar cache into SGPRs, the vector memory pipe that bounds the tree walk is not used at all, and what is left is the
+// reference's own Moller-Trumbore arithmetic (intersect.rs:62-98: same operations, same order, same tie rule as leaf_pred) at one triangle per ~70
+// vector instructions for 64 rays.  A list ends early once every lane holds a hit nearer than anything the rest of the list can offer.
+// Output: what trace_kernel<PRIMARY> writes — hit flags and hit records of the chunk's region; culled chunks are skipped alike.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef const u32x4_t __attribute__((address_space(4))) * const_u4_ptr;    // constant address space: a wave-uniform address loads through the scalar cache
+typedef const u32x2_t __attribute__((address_space(4))) * const_u2_ptr;
+template <bool COUNT, bool CONFIRM>
+__global__ __launch_bounds__(kBlock) void raster_kernel(DScene sc, DCamera cam, DPass ps, float4* __restrict__ hits, uint32_t* cursor,
+                                                        const uint32_t* __restrict__ film_n, DCounters* counters)
+{
+    const int lane = lane_id();
+    const const_u2_ptr tile_ofs = (const_u2_ptr)(uintptr_t)cam.tile_ofs, entries = (const_u2_ptr)(uintptr_t)cam.tile_entries;
+    const const_u4_ptr tris = (const_u4_ptr)(uintptr_t)sc.tris;
+    unsigned long long acc_tris = 0;
+    PullState pull; uint32_t chunk = 0u;
+    while (pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
+        const uint32_t n = min(ps.chunk, ps.nsamples - chunk * ps.chunk);
+        if (chunk_is_culled(cam, ps, chunk, n)) continue;               // the shade kernel makes the same decision
+        for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool valid = i < n;
+            const uint32_t gi = chunk * ps.chunk + (valid ? i : i0);
+            uint32_t pixel, sampleno; f3 o, d;
+            primary_sample(cam, ps, film_n, gi, pixel, sampleno, o, d);
+            // the tile of these 64 samples (wave-uniform: the host built the bins for exactly this layout)
+            uint32_t s0, p0, first_row, nr, x, y;
+            sample_of(ps, chunk * ps.chunk + i0, s0, p0);
+            pass_column(ps, cam.width, p0, first_row, nr, x, y);
+            const uint32_t tile = bcast_first((pass_row(ps, first_row) / cam.tile_rg) * cam.tile_nblocks + x / cam.tile_cols);
+            const u32x2_t oc = tile_ofs[tile];
+            const float dlen = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z) * 1.00001f;      // t * |d| = distance from the camera; a little long: the early out stays on the safe side
+            float bt = __builtin_inff(), bu = 0.0f, bv = 0.0f; uint32_t bprim = kMiss;
+            for (uint32_t e = 0; e < oc.y; ++e) {
+                const u32x2_t en = entries[oc.x + e];
+                // nothing from here on is nearer than en.y (the list is sorted): done when every lane's hit is nearer still
+                if (__ballot(valid && !(bt * dlen < __uint_as_float(en.y))) == 0ull) break;
+                const uint32_t ti = en.x * 3u;
+                const u32x4_t q0 = tris[ti], q1 = tris[ti + 1u], q2 = tris[ti + 2u];
+                const f3 v0 = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+                const f3 v0v1 = mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)), v0v2 = mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
+                // Moller-Trumbore "late out", intersect.rs:62-98, same operation order (leaf_pred)
+                const f3 pvec = cross3(d, v0v2);
+                const float det = dot3(v0v1, pvec);
+                const float inv_det = div_rn(1.0f, det);
+                const f3 tvec = sub3(o, v0);
+                const float u = dot3(tvec, pvec) * inv_det;
+                const f3 qvec = cross3(tvec, v0v1);
+                const float v = dot3(d, qvec) * inv_det;
+                const float t = dot3(v0v2, qvec) * inv_det;
+                const bool ok = !(fabsf(det) < 1.1920929e-7f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(t < 0.0f);
+                const uint32_t prim = q0.w;
+                const bool better = ok & ((bprim == kMiss) | (t < bt) | ((t == bt) & (prim < bprim)));
+                bt = better ? t : bt; bu = better ? u : bu; bv = better ? v : bv; bprim = better ? prim : bprim;
+            }
+            if (COUNT) acc_tris += (unsigned long long)oc.y * (unsigned long long)__popcll(__ballot(valid));
+            if (valid) {
+                const uint32_t rec = chunk * ps.region + i;
+                bool hit = bprim != kMiss;
+                if (CONFIRM && sc.oct_single_leaf && hit)       // a one-leaf octree: its whole answer is the contains test on the root cube (trace_wave)
+                    hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]), add3(o, vscale(d, bt)));
+                st1<1>((uint32_t*)((char*)ps.hit_prim + ((size_t)rec << 2)), hit ? bprim : kMiss);
+                if (hit) st4<1>((float4*)((char*)hits + ((size_t)rec << 4)), make_float4(bt, bu, bv, __uint_as_float(bprim)));
+            }
+        }
+    }
+    if (COUNT && lane == 0 && acc_tris) atomicAdd(&counters[global_wave_id() % kShards].tris_tested, acc_tris);
+}
+
 // ---- trace with the reference-exact octree intersector (parity path, MI355RT_FLAG_OCTREE_SEMANTICS) ----
 template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock) void trace_octree_kernel(DScene sc, DCamera cam, DPass ps,
@@ -1369,6 +1442,18 @@ hipError_t launch_trace(hipStream_t stream, int num_cus, int blocks_per_cu_cap, 
     if (confirm) return count ? launch_trace_variant<false, true, true>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, true>(MI355RT_TRACE_ARGS);
     return count ? launch_trace_variant<false, true, false>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, false>(MI355RT_TRACE_ARGS);
 #undef MI355RT_TRACE_ARGS
+}
+
+hipError_t launch_raster(hipStream_t stream, int num_cus, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
+                         void* hits, uint32_t* cursor, const uint32_t* film_n, DCounters* counters)
+{
+    // persistent grid like the trace launch; no LDS, few registers: 8 blocks per CU
+    const dim3 grid((unsigned)(num_cus * 8)), block(kBlock);
+    if (confirm) { if (count) hipLaunchKernelGGL((raster_kernel<true, true>), grid, block, 0, stream, sc, cam, ps, (float4*)hits, cursor, film_n, counters);
+                   else hipLaunchKernelGGL((raster_kernel<false, true>), grid, block, 0, stream, sc, cam, ps, (float4*)hits, cursor, film_n, counters); }
+    else { if (count) hipLaunchKernelGGL((raster_kernel<true, false>), grid, block, 0, stream, sc, cam, ps, (float4*)hits, cursor, film_n, counters);
+           else hipLaunchKernelGGL((raster_kernel<false, false>), grid, block, 0, stream, sc, cam, ps, (float4*)hits, cursor, film_n, counters); }
+    return hipGetLastError();
 }
 
 hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,

@@ -9,6 +9,9 @@ namespace mi355rt {
 hipError_t launch_trace(hipStream_t stream, int num_cus, int blocks_per_cu_cap, bool primary, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
                         const void* in_q, const void* in_counts, void* hits, uint32_t* cursor,
                         float* slot_L, const uint32_t* film_n, DCounters* counters);
+// the primary rays' closest hits through the screen-space triangle bins (cam.tile_ofs != null); same outputs as the primary trace launch
+hipError_t launch_raster(hipStream_t stream, int num_cus, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
+                         void* hits, uint32_t* cursor, const uint32_t* film_n, DCounters* counters);
 hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
                                const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n);
 hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,

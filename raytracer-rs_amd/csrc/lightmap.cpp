@@ -153,6 +153,19 @@ void build_light_map(const float* tri_verts, uint32_t ntri, const float light[3]
     }
 }
 
+double point_triangle_distance_lower(const double p[3], const float* v)
+{
+    const V3 L = { p[0], p[1], p[2] };
+    const V3 P[3] = { sub({ v[0], v[1], v[2] }, L), sub({ v[3], v[4], v[5] }, L), sub({ v[6], v[7], v[8] }, L) };
+    double dmin = origin_triangle_distance(P[0], P[1], P[2]);
+    const double size = std::max(len(sub(P[1], P[0])), std::max(len(sub(P[2], P[0])), len(sub(P[2], P[1]))));
+    const double near_vertex = std::min(len(P[0]), std::min(len(P[1]), len(P[2])));
+    const double lower = std::max(near_vertex - size, 0.0);
+    if (!(dmin >= 0.0) || !std::isfinite(dmin)) dmin = lower;
+    dmin = std::min(std::max(dmin, lower), near_vertex);
+    return dmin == dmin ? dmin : 0.0;
+}
+
 uint64_t light_map_work(const float* tri_verts, uint32_t ntri, const float light[3], uint32_t res)
 {
     // texel updates build_light_map would make at resolution `res`: the solid angle of every triangle's bounding cone, in texels (6 R^2 texels = 4 pi)

@@ -19,6 +19,8 @@ struct LightMap {
 // tri_verts: ntri * 9 world-space floats; pad: world-space padding of every triangle (what the triangle test's rounding may add to it)
 void build_light_map(const float* tri_verts, uint32_t ntri, const float light[3], double pad, uint32_t res, LightMap& out);
 // estimate of the texel updates build_light_map makes at resolution `res` (to pick a resolution the build can afford)
+// distance from point p to the triangle (v0, v1, v2) given as 9 floats, in double; a degenerate triangle gets a LOWER bound
+double point_triangle_distance_lower(const double p[3], const float* tri9);
 uint64_t light_map_work(const float* tri_verts, uint32_t ntri, const float light[3], uint32_t res);
 
 }  // namespace mi355rt

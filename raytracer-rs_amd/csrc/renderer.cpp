@@ -337,6 +337,8 @@ Renderer::~Renderer()
     }
     if (trace_stream_) { (void)hipStreamSynchronize(trace_stream_); (void)hipStreamDestroy(trace_stream_); }
     for (void* p : allocs_) (void)hipFree(p);
+    if (d_tile_ofs_) (void)hipFree(d_tile_ofs_);
+    if (d_tile_entries_) (void)hipFree(d_tile_entries_);
     if (h_ldr_) (void)hipHostFree(h_ldr_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     comm_destroy();
@@ -449,7 +451,117 @@ bool Renderer::refresh_cull_mask(DCamera& c, const double inv[3][3], double pad,
     return true;
 }
 
-DCamera Renderer::device_camera()
+// Screen-space triangle bins for the primary rays (device_types.hpp, kernels.hip raster_kernel).  The 64 consecutive samples a wave takes are
+// 64 / sample_group pixels: tile_cols columns x row_group rows of one row group (kernels.hip, pass_column).  When every group of the pass's row list
+// is row_group CONSECUTIVE image rows starting at a multiple of row_group (always, for whole images and power-of-two stripes) a tile is a fixed
+// block of the image, and every triangle whose padded screen rectangle (the culling mask's) meets the tile's (dir_x, dir_y) footprint — computed
+// like chunk_is_culled computes a chunk's — goes on the tile's list, nearest first.  Any primary ray that hits a triangle has its direction inside
+// that triangle's rectangle, so the closest hit over the tile's list IS the closest hit over the scene.  Rebuilt with the mask when the camera
+// (or the layout) changes; scenes whose lists get long (tiny triangles: > 24 per tile on average) keep the BVH walk.
+bool Renderer::refresh_tile_bins(DCamera& c, const double inv[3][3], double pad, double zmin, const DPass& ps, const std::vector<uint32_t>& rows)
+{
+#define BINS_OUT(k) do { if (getenv("MI355RT_DEBUG_CULL")) fprintf(stderr, "[mi355rt] tile bins: not built (exit %d)\n", k); return true; } while (0)
+    c.tile_ofs = nullptr; c.tile_entries = nullptr; c.tile_cols = c.tile_rg = c.tile_nblocks = 0;
+    if (c.cull_valid == 0 || bvh.tris.empty() || bvh.tris.size() > (2u << 20) || getenv("MI355RT_NO_RASTER")) BINS_OUT(1);
+    const uint32_t W = cfg.width, H = cfg.height, rg = ps.row_group, G = ps.sample_group;
+    if (ps.use_explicit || G == 0 || 64u % G || (64u / G) % rg || ps.chunk % 64u) BINS_OUT(2);
+    const uint32_t cols = 64u / G / rg;
+    if (W % cols || rows.size() % rg || rows.empty() || ps.npix != rows.size() * (size_t)W) BINS_OUT(3);
+    for (size_t i = 0; i < rows.size(); i += rg) {                      // every group: rg consecutive image rows from a multiple of rg
+        if (rows[i] % rg) BINS_OUT(4);
+        for (uint32_t k = 1; k < rg; ++k) if (rows[i + k] != rows[i] + k) BINS_OUT(5);
+    }
+    const bool fix_row = (ps.flags & 1u) != 0;
+    std::vector<float> key(c.rot, c.rot + 16);
+    key.insert(key.end(), c.origin, c.origin + 3); key.push_back(c.max_x); key.push_back(c.max_y);
+    key.push_back((float)cols); key.push_back((float)rg); key.push_back(fix_row ? 1.0f : 0.0f);
+    const uint32_t nblocks = W / cols, ngroups = (H + rg - 1) / rg;
+    auto publish = [&]() { c.tile_ofs = d_tile_ofs_; c.tile_entries = d_tile_entries_; c.tile_cols = cols; c.tile_rg = rg; c.tile_nblocks = nblocks; };
+    if (key == bins_key_) { if (bins_valid_) publish(); return true; }
+    bins_key_ = key; bins_valid_ = false;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const double mx = c.max_x, my = c.max_y;
+    const uint64_t vmax = fix_row ? (uint64_t)H - 1 : ((uint64_t)W * H - 1) / H;
+    struct Ref { uint32_t tile; float dmin; uint32_t tri; };
+    std::vector<Ref> refs;
+    refs.reserve(bvh.tris.size() * 6);
+    const double org[3] = { c.origin[0], c.origin[1], c.origin[2] };
+    for (size_t k = 0; k < bvh.tris.size(); ++k) {
+        const BvhTri& t = bvh.tris[k];
+        float v9[9];
+        for (int a = 0; a < 3; ++a) { v9[a] = t.v0[a]; v9[3 + a] = t.v0[a] + t.e1[a]; v9[6 + a] = t.v0[a] + t.e2[a]; }
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int v = 0; v < 3; ++v) for (int q = 0; q < 8; ++q) {          // the vertices' padded cubes, as in the culling mask
+            double w[3];
+            for (int a = 0; a < 3; ++a) w[a] = (double)v9[3 * v + a] + ((q >> a) & 1 ? pad : -pad) - org[a];
+            const double vx = w[0] * inv[0][0] + w[1] * inv[1][0] + w[2] * inv[2][0];
+            const double vy = w[0] * inv[0][1] + w[1] * inv[1][1] + w[2] * inv[2][1];
+            const double vz = w[0] * inv[0][2] + w[1] * inv[1][2] + w[2] * inv[2][2];
+            if (!(vz > zmin)) BINS_OUT(7);
+            const double dx = vx / vz, dy = -vy / vz;
+            x0 = std::min(x0, dx); x1 = std::max(x1, dx); y0 = std::min(y0, dy); y1 = std::max(y1, dy);
+        }
+        const double ex = 1e-4 * (x1 - x0) + 1e-6, ey = 1e-4 * (y1 - y0) + 1e-6;
+        // columns cu and row indices cv (kernels.hip, primary_sample) whose jitter range [cu, cu + 1) / W, [cv, cv + 1) / H can reach the rectangle;
+        // 1/100 of a column of slack covers the f32 rounding of the kernel's own expressions
+        const double fx0 = (x0 - ex + mx) / (2.0 * mx) * W - 0.01, fx1 = (x1 + ex + mx) / (2.0 * mx) * W + 0.01;
+        const double fy0 = (y0 - ey + my) / (2.0 * my) * H - 0.01, fy1 = (y1 + ey + my) / (2.0 * my) * H + 0.01;
+        if (fx1 < 0.0 || fx0 >= (double)W || fy1 < 0.0 || fy0 > (double)vmax + 1.0) continue;
+        const uint64_t c0 = (uint64_t)std::max(0.0, std::floor(fx0)), c1 = (uint64_t)std::min((double)W - 1.0, std::floor(fx1));
+        const uint64_t v0 = (uint64_t)std::max(0.0, std::floor(fy0)), v1 = (uint64_t)std::min((double)vmax, std::floor(fy1));
+        if (c1 < c0 || v1 < v0) continue;
+        // image rows whose pixels of columns c0..c1 have cv in [v0, v1]: cv = (row * W + x) / H, or the row itself with the fixed row index
+        uint64_t r0, r1;
+        if (fix_row) { r0 = v0; r1 = std::min<uint64_t>(v1, H - 1); }
+        else {
+            const uint64_t lo = v0 * H, hi = (v1 + 1) * H - 1;                           // row * W + x in [lo, hi] for some x in [c0, c1]
+            r0 = lo > c1 ? (lo - c1 + W - 1) / W : 0; r1 = hi >= c0 ? (hi - c0) / W : 0;
+            if (hi < c0) continue;
+            r1 = std::min<uint64_t>(r1, H - 1);
+        }
+        if (r1 < r0) continue;
+        const double org_d = point_triangle_distance_lower(org, v9);
+        const float dmin = (float)std::max((org_d - pad) * (1.0 - 1e-6), 0.0);
+        const float dmin_lo = (double)dmin > std::max((org_d - pad) * (1.0 - 1e-6), 0.0) ? std::nextafterf(dmin, 0.0f) : dmin;
+        for (uint64_t g = r0 / rg; g <= r1 / rg && g < ngroups; ++g) {
+            const uint64_t ra = g * rg, rb = std::min<uint64_t>(ra + rg - 1, H - 1);
+            for (uint64_t b = c0 / cols; b <= c1 / cols; ++b) {
+                const uint64_t xa = b * cols, xb = xa + cols - 1;
+                // the tile's own cv range (every pixel of it lies between its first and its last): must meet [v0, v1]
+                const uint64_t ta = fix_row ? ra : (ra * W + xa) / H, tb = fix_row ? rb : (rb * W + xb) / H;
+                if (tb < v0 || ta > v1) continue;
+                refs.push_back(Ref{ (uint32_t)(g * nblocks + b), dmin_lo, (uint32_t)k });
+            }
+        }
+    }
+    const size_t ntiles = (size_t)nblocks * ngroups;
+    std::vector<uint2> ofs(ntiles, make_uint2(0u, 0u));
+    for (const Ref& r : refs) ++ofs[r.tile].y;
+    size_t live = 0; uint32_t run = 0;
+    for (uint2& o : ofs) { o.x = run; run += o.y; live += o.y != 0; o.y = 0; }
+    if (refs.size() > ((size_t)64 << 20) || (live && refs.size() > 24 * live)) BINS_OUT(8);     // long lists: the BVH walk is the better search
+    std::vector<uint2> entries(std::max<size_t>(refs.size(), 1));
+    for (const Ref& r : refs) { uint2& o = ofs[r.tile]; uint32_t bits; std::memcpy(&bits, &r.dmin, 4); entries[o.x + o.y++] = make_uint2(r.tri, bits); }
+    for (const uint2& o : ofs) if (o.y > 1)
+        std::sort(entries.begin() + o.x, entries.begin() + o.x + o.y, [](const uint2& a, const uint2& b) { return a.y != b.y ? a.y < b.y : a.x < b.x; });   // non-negative floats order like their bits
+    if (!bind()) return false;
+    // kernels of earlier calls may still read the old bins (as with the mask): wait, then replace
+    (void)hipStreamSynchronize(stream_);
+    if (trace_stream_) (void)hipStreamSynchronize(trace_stream_);
+    for (Slice& sl : slices_) if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (ofs.size() > tile_ofs_cap_) { if (d_tile_ofs_) (void)hipFree(d_tile_ofs_); d_tile_ofs_ = nullptr; tile_ofs_cap_ = 0; if (hipMalloc((void**)&d_tile_ofs_, ofs.size() * sizeof(uint2)) != hipSuccess) { d_tile_ofs_ = nullptr; BINS_OUT(9); } tile_ofs_cap_ = ofs.size(); }
+    if (entries.size() > tile_entries_cap_) { if (d_tile_entries_) (void)hipFree(d_tile_entries_); d_tile_entries_ = nullptr; tile_entries_cap_ = 0; const size_t cap = entries.size() + entries.size() / 4; if (hipMalloc((void**)&d_tile_entries_, cap * sizeof(uint2)) != hipSuccess) { d_tile_entries_ = nullptr; BINS_OUT(10); } tile_entries_cap_ = cap; }
+    if (hipMemcpy(d_tile_ofs_, ofs.data(), ofs.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) BINS_OUT(11);
+    if (hipMemcpy(d_tile_entries_, entries.data(), entries.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) BINS_OUT(12);
+    bins_valid_ = true; bins_entries_ = refs.size();
+    bins_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    publish();
+    if (getenv("MI355RT_DEBUG_CULL")) fprintf(stderr, "[mi355rt] tile bins: %u x %u tiles of %u columns x %u rows, %zu live, %zu entries (%.1f per live tile), %.1f ms\n", nblocks, ngroups, cols, rg, live, refs.size(), live ? (double)refs.size() / live : 0.0, bins_ms_);
+    return true;
+}
+#undef BINS_OUT
+
+DCamera Renderer::device_camera(const DPass* layout, const std::vector<uint32_t>* rows)
 {
     DCamera c;
     std::memcpy(c.rot, camera.rotation().e, sizeof c.rot);
@@ -463,6 +575,7 @@ DCamera Renderer::device_camera()
     c.cull_valid = 0;
     std::memset(c.cull_rect, 0, sizeof c.cull_rect);
     c.cull_mask = nullptr; c.mask_x0 = c.mask_y0 = 0.0f; c.mask_inv_cx = c.mask_inv_cy = 0.0f;
+    c.tile_ofs = nullptr; c.tile_entries = nullptr; c.tile_cols = c.tile_rg = c.tile_nblocks = 0;
     if (!cull_boxes_.empty() && mode_ != kModeOctreeWalk && !getenv("MI355RT_NO_CULL")) {
         const float* e = c.rot;
         const double m[3][3] = { { e[0], e[1], e[2] }, { e[4], e[5], e[6] }, { e[8], e[9], e[10] } };
@@ -500,6 +613,7 @@ DCamera Renderer::device_camera()
             // the mask pads every vertex by ten times what the BVH pads its boxes with (bvh.cpp: 2e-5 of the diagonal) — the same assumption about
             // the triangle test's rounding that the traversal itself rests on, with a wider margin
             if (front) (void)refresh_cull_mask(c, inv, 2e-4 * std::sqrt(diag) + 1e-7, 1e-6 * std::sqrt(diag));
+            if (front && layout && rows) (void)refresh_tile_bins(c, inv, 2e-4 * std::sqrt(diag) + 1e-7, 1e-6 * std::sqrt(diag), *layout, *rows);
             if (getenv("MI355RT_DEBUG_CULL")) { fprintf(stderr, "[mi355rt] cull rects %u front %d max_x %g\n", n, (int)front, c.max_x); for (uint32_t k = 0; k < n; ++k) fprintf(stderr, "   x [%g, %g] y [%g, %g]\n", c.cull_rect[k][0], c.cull_rect[k][1], c.cull_rect[k][2], c.cull_rect[k][3]); }
         }
     }
@@ -636,7 +750,9 @@ bool Renderer::pass_begin(PassRun& run, Slice& sl, const uint32_t* d_rows, uint3
     if (nsamples == 0) return true;
     if (!ensure_pass_capacity(sl, nsamples)) return false;
     describe_pass(run.ps, sl, d_rows, row0, row_wrap, npix, nsamples, chunk_, explicit_sample, epixel, esample);
-    run.cam = device_camera();
+    // the tile bins of the primary rays need a pass that walks the slice's whole row list (render(); not the odd row windows of the other callers)
+    const bool whole = !explicit_sample && d_rows == sl.d_rows && row0 == 0 && nrows == sl.rows.size() && row_wrap == 0xFFFFFFFFu;
+    run.cam = device_camera(whole ? &run.ps : nullptr, whole ? &sl.rows : nullptr);
     run.rounds = cfg.recursions + 2;
     // the work cursors: zeroed at creation and again by the resolve kernel of every pass that ran to its end (pass_end)
     if (!sl.ctrl_clean) HIP_TRY(hipMemsetAsync(sl.d_ctrl, 0, kMaxRounds * kCtrlWordsPerRound * 4, sl.stream));
@@ -678,6 +794,9 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
     else {
         DPass pr = ps;
         if (r == 0) pr.refill_threshold = refill_primary_;             // primary rays: see describe_pass
+        if (r == 0 && cam.tile_ofs != nullptr)                         // the primary rays' closest hits from the screen-space triangle bins instead of the tree
+            HIP_TRY(launch_raster(tst, num_cus_, count, mode_ == kModeConfirm, dscene_, cam, ps, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, d_film_n_, d_counters_));
+        else
         HIP_TRY(launch_trace(tst, num_cus_, trace_blocks_per_cu, r == 0, count, mode_ == kModeConfirm, dscene_, cam, pr, in_q, in_c, sl.d_hits, sl.d_ctrl + r * kCtrlWordsPerRound, sl.d_slot_L, d_film_n_, d_counters_));
     }
     if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], tst)); ev_used_ += 2; }

@@ -72,6 +72,12 @@ public:
     std::vector<float> mask_key_;        // the camera the mask on the device was built for (rot, origin, max_x, max_y); empty: none
     float mask_dom_[4] = { 0, 0, 0, 0 }; // its domain: x0, y0, 1 / cell width, 1 / cell height
     bool mask_valid_ = false;
+    uint2* d_tile_ofs_ = nullptr; uint2* d_tile_entries_ = nullptr;     // screen-space triangle bins of the primary rays (device_types.hpp), rebuilt with the mask
+    size_t tile_entries_cap_ = 0, tile_ofs_cap_ = 0;
+    std::vector<float> bins_key_;        // camera + layout the bins on the device were built for
+    uint32_t bins_layout_[3] = { 0, 0, 0 };   // tile_cols, tile_rg, tile_nblocks
+    bool bins_valid_ = false;
+    double bins_ms_ = 0.0; size_t bins_entries_ = 0;
     uint32_t oct_stats_[8] = { 0 };       // the reference's octree: nodes, inner, leaves, empty, depth, triangle refs
     double build_ms_[2] = { 0.0, 0.0 };   // build times inside create (wall): BVH (host binned SAH, or the device build), octree (SAT, host)
     double light_map_ms_ = 0.0;           // build time of the lights' depth cube maps inside create
@@ -125,7 +131,9 @@ private:
     bool fetch_counts(uint64_t primary, bool timed_call);
     bool queue_counts_copy();
     void mark_dirty_window(uint32_t first, uint32_t total);
-    DCamera device_camera();
+    // layout + rows: the pass whose primary rays the tile bins are for and the (host copy of the) row list it walks (null: no bins needed)
+    DCamera device_camera(const DPass* layout = nullptr, const std::vector<uint32_t>* rows = nullptr);
+    bool refresh_tile_bins(DCamera& c, const double inv[3][3], double pad, double zmin, const DPass& ps, const std::vector<uint32_t>& rows);
     bool refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin);
     void collect_cull_boxes();
     void build_sample_table(std::vector<float>& table4);
