@@ -634,6 +634,53 @@ def test_light_depth_maps_never_change_a_frame(pkg, scenes, oracle, sem3, monkey
         assert ca == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"])
 
 
+@pytest.mark.parametrize("name,w,h,stripe", [("thai2", 960, 544, None), ("thai2", 640, 360, (2, 1, 3)), ("ico2", 512, 256, None), ("4boxes", 320, 240, (4, 0, 2)),
+                                              ("ico3_tex", 256, 256, None), ("thai2", 322, 250, None)])
+def test_primary_rays_through_the_tile_bins_equal_the_tree_walk(pkg, scenes, sem, monkeypatch, name, w, h, stripe):
+    """The primary rays' closest hits come from the screen-space triangle bins (raster_kernel) when the pass layout allows it, from the BVH walk
+    otherwise (MI355RT_NO_RASTER; odd widths / heights like 322 x 250 whose tiles would straddle row groups).  Both give the same film, pixels and
+    counters — whole images and row stripes, both shipped semantics, with and without the row-index quirk, before and after camera moves (the bins
+    are rebuilt) and with several passes per frame."""
+    kw = {}
+    if stripe is not None:
+        kw = dict(stripe_rows=stripe[0], stripe_rank=stripe[1], stripe_world=stripe[2])
+    runs = {}
+    for mode in ("bins", "walk"):
+        monkeypatch.delenv("MI355RT_NO_RASTER", raising=False)
+        if mode == "walk":
+            monkeypatch.setenv("MI355RT_NO_RASTER", "1")
+        rt = make(pkg, scenes, name, w, h, seed=6, flags=sem.gpu, samples_per_pass=2, **kw)
+        out = []
+        rt.set_flags(sem.gpu | pkg.FLAG_COUNT_STEPS)
+        nodes = rt.render(2).nodes_visited                      # instrumented: the bins take the primary rays' node visits away
+        rt.set_flags(sem.gpu); rt.film.clear()
+        c = rt.render(5)                                        # 3 passes (2 + 2 + 1 samples per pixel)
+        out.append((rt.film.pixel_datas(), (c.primary, c.bounce, c.shadow, c.primary_hits, c.primary_culled)))
+        rt.camera.move_rel(-0.3, 0.2, 0.5); rt.camera.add_x_angle(0.04); rt.camera.add_y_angle(0.11)
+        rt.film.clear()
+        c = rt.render(2)
+        out.append((rt.film.pixel_datas(), (c.primary, c.bounce, c.shadow, c.primary_hits, c.primary_culled)))
+        rt.set_flags(sem.gpu | pkg.FLAG_FIX_ROW_INDEX)
+        c = rt.render(2)
+        out.append((rt.film.pixel_datas(), (c.primary, c.bounce, c.shadow, c.primary_hits, c.primary_culled)))
+        out.append(rt.get_tonemapped_pixels())
+        out.append(nodes)
+        runs[mode] = out
+        del rt
+    if (name, w) == ("thai2", 960):
+        assert runs["bins"][4] < runs["walk"][4]               # the bins were in use
+    elif w % 4 or h % 8:
+        assert runs["bins"][4] == runs["walk"][4]              # tiles would straddle row groups: both runs walked the tree
+    else:
+        assert runs["bins"][4] <= runs["walk"][4]
+    for a, b in zip(runs["bins"][:3], runs["walk"][:3]):
+        assert a[1] == b[1]
+        for x, y in zip(a[0], b[0]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.array_equal(runs["bins"][3], runs["walk"][3])
+    assert runs["bins"][0][1][3] > 0                            # something was hit
+
+
 def _random_scene(scenes, ntri, seed):
     """ntri small random triangles in a slab in front of the 4boxes camera (materials / light from 4boxes)."""
     rng = np.random.default_rng(seed)
