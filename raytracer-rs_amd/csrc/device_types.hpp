@@ -22,6 +22,7 @@ constexpr uint32_t kMaxCursors = 64;
 constexpr uint32_t kCtrlWordsPerRound = kMaxCursors * 16384;   // work cursors of one round, 64 KiB apart
 constexpr uint32_t kShadeCursorOffset = 128;                   // the shade launch of a round: 512 B after
 constexpr uint32_t kConfirmCursorOffset = 64;                  // the confirm launch of a round: its cursors sit 256 B after the trace launch's
+constexpr uint32_t kLiveCountOffset = 192;                     // round 0's cursor words + 768 B: how many chunks cursor k's live list holds (DPass::live)
 
 struct DMaterial { float r, g, b; uint32_t kind_tex; };       // kind_tex: bit 31 = texture, low bits = texture id
 struct DLight { float px, py, pz, cr, cg, cb;
@@ -107,6 +108,13 @@ struct DPass {
     uint32_t list_cap;        // shade kernel: LDS hit-list entries per wave (max radiance rays per chunk)
     uint32_t tail_chunks;     // trace kernel: the last tail_chunks chunks of every cursor's sequence are handed out in parts (host: chunks per wave; the launcher scales it by the waves per cursor)
     uint32_t tail_split_shift; // log2 of the parts a tail chunk is handed out in (0: whole chunks everywhere)
+    // Live chunks (round 3).  Most chunks of a pass hold no ray after the primary round (thai2: 70 % — culled, or nothing hit), and every later launch
+    // paid a pull, a count load and a loop set-up for each of them (1.35 ms per frame with every chunk empty).  The primary shade launch appends
+    // every chunk it leaves rays in to the list of cursor (chunk % ncursors): live[k * live_cap ...], length in live_count[k * 16384 + kLiveCountOffset];
+    // the launches of the later rounds hand out list entries instead of chunk numbers (pull_chunk).  null: every launch walks all chunks.
+    uint32_t* live;
+    uint32_t* live_count;
+    uint32_t live_cap;
 };
 
 struct DCounters {            // one set per render call, zeroed at its start

@@ -95,8 +95,15 @@ __device__ __forceinline__ uint32_t global_wave_id() { return blockIdx.x * kWave
 // Tried and dropped: a relaxed agent-scope load in front of the atomic (2.5x slower), 3/4 static + a
 // dynamic rest, several chunks per pull, draining more than 8 cursors, heaviest-chunks-first order.
 constexpr uint32_t kCursorStride = kCtrlWordsPerRound / kMaxCursors;   // u32 words between cursors (64 KiB): atomics to nearby lines serialise on one memory channel
-static_assert(kCursorStride == 16384 && kShadeCursorOffset == 2 * kConfirmCursorOffset, "cursor layout (device_types.hpp) and the reset loop of resolve_kernel");
+static_assert(kCursorStride == 16384 && kShadeCursorOffset == 2 * kConfirmCursorOffset && kLiveCountOffset == 3 * kConfirmCursorOffset, "cursor layout (device_types.hpp) and the reset loop of resolve_kernel");
+typedef const uint32_t __attribute__((address_space(4))) * const_u1_ptr;    // constant address space: a wave-uniform address loads through the scalar cache
 struct PullState { bool first = true; uint32_t shard = 0u, tries = 0u, left = 0u, part = 0xFFFFFFFFu; };
+// the live-chunk lists of a pass (DPass::live): cursor k hands out the entries of list k instead of the chunk numbers k, k + ncursors, ...
+struct LiveLists { const uint32_t* list = nullptr; const uint32_t* count = nullptr; uint32_t cap = 0u; };
+// (the build knobs that make the shade / confirm launches stride over ALL chunks switch the lists off for every launch: a launch that visits chunks the
+// others skipped would read ray counts nobody wrote)
+constexpr bool kLiveListsOk = kShadePullMode == 0u && kConfirmPullMode == 0u;
+__device__ __forceinline__ LiveLists live_lists(const DPass& ps) { LiveLists l; if (kLiveListsOk) { l.list = ps.live; l.count = ps.live_count; l.cap = ps.live_cap; } return l; }
 constexpr uint32_t kWholeChunk = 0xFFFFFFFFu;
 
 // tail / split (trace kernels only; 0 / 1 elsewhere): the LAST `tail` chunks of every cursor's sequence are handed out in `split`
@@ -105,8 +112,28 @@ constexpr uint32_t kWholeChunk = 0xFFFFFFFFu;
 // wave (one rank's share of a strong-scaled frame), a tenth of a full-size one (profiles/r03_notes.md).  Splitting only the tail keeps
 // the per-pull cost (count load, culling test, a colder start) off the bulk of the chunks.
 __device__ __forceinline__ bool pull_chunk(uint32_t* cursor, uint32_t nchunks, uint32_t mode, uint32_t ncursors, uint32_t group, PullState& st, uint32_t& chunk,
-                                           uint32_t tail = 0u, uint32_t split_shift = 0u)
+                                           uint32_t tail = 0u, uint32_t split_shift = 0u, const LiveLists live = LiveLists())
 {
+    if (mode == 4u && live.list != nullptr) {
+        // live lists: cursor k's sequence is list k (filled by the primary shade launch); otherwise as below
+        if (st.first) { st.first = false; st.shard = global_wave_id() % ncursors; }
+        const uint32_t max_tries = ncursors < 8u ? ncursors : 8u;
+        while (st.tries < max_tries) {
+            // (lists and counts were written by an EARLIER launch: wave-uniform addresses, read through the scalar cache, which every launch starts with empty)
+            const uint32_t len = ((const_u1_ptr)(uintptr_t)live.count)[(size_t)st.shard * kCursorStride + kLiveCountOffset];
+            uint32_t v = 0xFFFFFFFFu;
+            if (len != 0u) { if (lane_id() == 0) v = atomicAdd(&cursor[(size_t)st.shard * kCursorStride], 1u); v = bcast_first(v); }
+            uint32_t j = v; st.part = kWholeChunk;
+            if (tail != 0u && v != 0xFFFFFFFFu) {
+                const uint32_t head = len - (tail < len ? tail : len);
+                if (v >= head) { const uint32_t jj = v - head; j = head + (jj >> split_shift); st.part = jj & ((1u << split_shift) - 1u); }
+            }
+            if (j < len) { chunk = ((const_u1_ptr)(uintptr_t)live.list)[(size_t)st.shard * live.cap + j]; return true; }
+            st.shard = (st.shard + 1u) % ncursors;      // dry for good
+            ++st.tries;
+        }
+        return false;
+    }
     if (mode == 4u) {
         if (st.first) { st.first = false; st.shard = global_wave_id() % ncursors; }
         else if (st.left > 0u && chunk + 1u < nchunks) { --st.left; ++chunk; return true; }     // rest of the group pulled last time
@@ -429,7 +456,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                     if (!w_pull.first) { exhausted = true; break; }
                     w_pull.first = false; c = single_chunk;
                 }
-                else if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c, ps.tail_chunks, ps.tail_split_shift)) { exhausted = true; break; }
+                else if (!pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, w_pull, c, ps.tail_chunks, ps.tail_split_shift, PRIMARY ? LiveLists() : live_lists(ps))) { exhausted = true; break; }
                 // bcast_first: these are wave-uniform by construction; saying so keeps them in SGPRs
                 w_chunk = bcast_first(c); w_next = 0u;
                 if (PRIMARY) {
@@ -738,7 +765,7 @@ __global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel
     uint32_t cnt = 0u;                                // < 64 between the steps below
     // chunks are pulled like the trace kernel pulls them (the hits sit in a part of the image: static striding leaves waves idle)
     PullState pull; uint32_t chunk = 0u;
-    while (pull_chunk(cursor, ps.nchunks, kConfirmPullMode ? kConfirmPullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
+    while (pull_chunk(cursor, ps.nchunks, kConfirmPullMode ? kConfirmPullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk, 0u, 0u, PRIMARY ? LiveLists() : live_lists(ps))) {
         uint32_t n_rad = 0u, n_sh = 0u;
         if (PRIMARY) {
             n_rad = min(ps.chunk, ps.nsamples - chunk * ps.chunk);
@@ -1076,9 +1103,15 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? (WALK ? MI355RT_SHADE_PW_BLOCKS :
     unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
     // chunks are pulled from the round's cursors: the hits sit in a part of the image, culled / empty chunks cost nothing
     PullState pull; uint32_t chunk = 0u;
-    while (pull_chunk(cursor, ps.nchunks, kShadePullMode ? kShadePullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
+    while (pull_chunk(cursor, ps.nchunks, kShadePullMode ? kShadePullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk, 0u, 0u, PRIMARY ? LiveLists() : live_lists(ps))) {
         uint32_t o_rad, o_sh;
         shade_chunk<PRIMARY, LinearList, WALK>(sc, cam, ps, level, chunk, list, in_q, PRIMARY ? 0u : in_counts[chunk].x, o_rad, o_sh, hits, out_q, out_counts, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
+        // a chunk that leaves the primary round with rays goes on the live list of its cursor: the later launches of the pass visit only those (DPass::live)
+        if (PRIMARY && kLiveListsOk && ps.live != nullptr && (o_rad | o_sh) != 0u && lane_id() == 0) {
+            const uint32_t k = chunk % ps.ncursors;
+            const uint32_t at = atomicAdd(&ps.live_count[(size_t)k * kCursorStride + kLiveCountOffset], 1u);
+            ps.live[(size_t)k * ps.live_cap + at] = chunk;
+        }
     }
     flush_shade_counters(counters, wave, acc_bounce, acc_shadow, PRIMARY ? acc_hits : 0ull);
 }
@@ -1119,8 +1152,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
 {
     // last kernel of a pass: leave the pass's work cursors zeroed for the next one (960 words; a 20 MiB memset otherwise)
     if (ctrl != nullptr && blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < kMaxRounds * kMaxCursors * 3u; i += blockDim.x)
-            ctrl[(size_t)(i / (kMaxCursors * 3u)) * kCtrlWordsPerRound + (size_t)((i / 3u) % kMaxCursors) * kCursorStride + (i % 3u) * kConfirmCursorOffset] = 0u;
+        for (uint32_t i = threadIdx.x; i < kMaxRounds * kMaxCursors * 4u; i += blockDim.x)     // trace, confirm, shade cursors and the live count of every (round, cursor)
+            ctrl[(size_t)(i / (kMaxCursors * 4u)) * kCtrlWordsPerRound + (size_t)((i / 4u) % kMaxCursors) * kCursorStride + (i % 4u) * kConfirmCursorOffset] = 0u;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = gid % kResolveLanes;
     const bool live = gid / kResolveLanes < ps.npix;

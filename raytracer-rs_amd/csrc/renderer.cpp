@@ -631,6 +631,7 @@ void Renderer::free_pass_buffers()
         }
         if (sl.d_slot_L) { (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; }
         if (sl.d_sample_slot) { (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr; }
+        if (sl.d_live) { (void)hipFree(sl.d_live); sl.d_live = nullptr; }
         if (sl.d_slot_ps) { (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr; }
         if (sl.d_hits) { (void)hipFree(sl.d_hits); sl.d_hits = nullptr; }
         if (sl.d_hit_prim) { (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr; }
@@ -646,7 +647,7 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
     if (sl.capacity) {          // grow: release this slice's buffers only
         for (int i = 0; i < 2; ++i) { (void)hipFree(sl.d_queue[i]); sl.d_queue[i] = nullptr; (void)hipFree(sl.d_chunk_counts[i]); sl.d_chunk_counts[i] = nullptr; }
         (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr;
-        (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr;
+        (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr; (void)hipFree(sl.d_live); sl.d_live = nullptr;
         (void)hipFree(sl.d_hits); sl.d_hits = nullptr; (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr;
         sl.capacity = 0; sl.bytes = 0; sl.guards.clear();
     }
@@ -676,6 +677,7 @@ bool Renderer::ensure_pass_capacity(Slice& sl, size_t nsamples)
     HIP_ALLOC(pass_alloc((void**)&sl.d_slot_L, nchunks * chunk_ * nodes_per_sample * std::max(nlights_, 1u) * 12));
     HIP_ALLOC(pass_alloc((void**)&sl.d_sample_slot, nchunks * chunk_ * 4));
     HIP_ALLOC(pass_alloc((void**)&sl.d_slot_ps, nchunks * chunk_ * 8));
+    HIP_ALLOC(pass_alloc((void**)&sl.d_live, (nchunks + kMaxCursors) * 4));
     sl.capacity = nsamples;
     sl.queue_records = records;
     sl.count_entries = count_entries;
@@ -736,6 +738,13 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     ps.tail_chunks = 2; if (const char* e = getenv("MI355RT_TAIL_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 64) ps.tail_chunks = (uint32_t)v; }
     ps.tail_split_shift = 2; if (const char* e = getenv("MI355RT_TAIL_SPLIT")) { int v = atoi(e); if (v >= 0 && v <= 4) ps.tail_split_shift = (uint32_t)v; }
     ps.ncursors = 64; if (const char* e = getenv("MI355RT_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= (int)kMaxCursors) ps.ncursors = (uint32_t)v; }
+    // live-chunk lists (device_types.hpp): with the cursor scheme the wavefront launches use by default, and the chunk size the buffers were sized for.
+    // Not with the direct octree walk: its trace launch strides over ALL chunks, and the ray counts of the chunks the shade launches no longer visit
+    // are whatever an earlier pass left there.
+    ps.live = nullptr; ps.live_count = nullptr; ps.live_cap = 0;
+    if (ps.pull_mode == 4u && ps.pull_group == 1u && chunk == chunk_ && sl.d_live != nullptr && !explicit_sample && mode_ != kModeOctreeWalk && !getenv("MI355RT_NO_LIVE")) {
+        ps.live = sl.d_live; ps.live_count = sl.d_ctrl; ps.live_cap = (ps.nchunks + ps.ncursors - 1u) / ps.ncursors;
+    }
 }
 
 // A wavefront pass in three steps, so that a frame can interleave the rounds of its slices (render()):

@@ -110,6 +110,7 @@ private:
         float* d_slot_L = nullptr;
         void* d_slot_ps = nullptr;               // light-term slot -> (pixel, sample number) of its sample (uint2)
         uint32_t* d_sample_slot = nullptr;       // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
+        uint32_t* d_live = nullptr;              // live-chunk lists of the pass, one per work cursor (DPass::live)
         size_t capacity = 0;                     // samples
         size_t queue_records = 0;
         size_t count_entries = 0;                // entries of each d_chunk_counts array

@@ -32,7 +32,10 @@ def _rank(rank, world, port, q):
     rt.render(SPP)
     fg_dev = st.FrameGather(H, W, STRIPE, world, "cuda")
     stripe = fg_dev.stripe_buffer("cuda")
-    rt.tonemap_owned_rows_device(stripe.data_ptr(), rows.size * W)          # the device-pointer entry bench.py uses
+    # torch fills the buffer with zeros on ITS stream, asynchronously; the library writes it on its own: ordered through torch's stream, as bench.py
+    # does (without this the zero fill could land after the pixels — seen once in a loaded suite run)
+    rt.tonemap_owned_rows_device(stripe.data_ptr(), rows.size * W, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     fg = st.FrameGather(H, W, STRIPE, world, "cpu")
     frame = fg.gather(dist, stripe.cpu()).numpy().view(np.uint32).copy()
     ok = True
