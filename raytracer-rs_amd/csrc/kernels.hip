@@ -578,13 +578,59 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef const u32x4_t __attribute__((address_space(4))) * const_u4_ptr;    // constant address space: a wave-uniform address loads through the scalar cache
 typedef const u32x2_t __attribute__((address_space(4))) * const_u2_ptr;
+// closest hit of the primary rays of ONE tile: the 64 samples from sample i0 of `chunk` on (lane l: sample i0 + l; valid: it exists).  Every lane
+// regenerates its ray; (bt, bu, bv, bprim) is its closest hit over the tile's list (kMiss: none).  Returns the number of list entries tested.
+__device__ __forceinline__ uint32_t raster_tile(const DScene& sc, const DCamera& cam, const DPass& ps, const uint32_t* __restrict__ film_n, uint32_t chunk, uint32_t i0, bool valid,
+                                                f3& o, f3& d, float& bt, float& bu, float& bv, uint32_t& bprim)
+{
+    const const_u2_ptr tile_ofs = (const_u2_ptr)(uintptr_t)cam.tile_ofs, entries = (const_u2_ptr)(uintptr_t)cam.tile_entries;
+    const const_u4_ptr tris = (const_u4_ptr)(uintptr_t)sc.tris;
+    const uint32_t gi = chunk * ps.chunk + i0 + (valid ? (uint32_t)lane_id() : 0u);
+    uint32_t pixel, sampleno;
+    primary_sample(cam, ps, film_n, gi, pixel, sampleno, o, d);
+    // the tile of these 64 samples (wave-uniform: the host built the bins for exactly this layout)
+    uint32_t s0, p0, first_row, nr, x, y;
+    sample_of(ps, chunk * ps.chunk + i0, s0, p0);
+    pass_column(ps, cam.width, p0, first_row, nr, x, y);
+    const uint32_t tile = bcast_first((pass_row(ps, first_row) / cam.tile_rg) * cam.tile_nblocks + x / cam.tile_cols);
+    const u32x2_t oc = tile_ofs[tile];
+    const float dlen = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z) * 1.00001f;      // t * |d| = distance from the camera; a little long: the early out stays on the safe side
+    bt = __builtin_inff(); bu = 0.0f; bv = 0.0f; bprim = kMiss;
+    uint32_t tested = 0u;
+    for (uint32_t e = 0; e < oc.y; ++e) {
+        const u32x2_t en = entries[oc.x + e];
+        // nothing from here on is nearer than en.y (the list is sorted): done when every lane's hit is nearer still
+        if (__ballot(valid && !(bt * dlen < __uint_as_float(en.y))) == 0ull) break;
+        ++tested;
+        const uint32_t ti = en.x * 3u;
+        const u32x4_t q0 = tris[ti], q1 = tris[ti + 1u], q2 = tris[ti + 2u];
+        const f3 v0 = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+        const f3 v0v1 = mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)), v0v2 = mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
+        // Moller-Trumbore "late out", intersect.rs:62-98, same operation order (leaf_pred)
+        const f3 pvec = cross3(d, v0v2);
+        const float det = dot3(v0v1, pvec);
+        const float inv_det = div_rn(1.0f, det);
+        const f3 tvec = sub3(o, v0);
+        const float u = dot3(tvec, pvec) * inv_det;
+        const f3 qvec = cross3(tvec, v0v1);
+        const float v = dot3(d, qvec) * inv_det;
+        const float t = dot3(v0v2, qvec) * inv_det;
+        const bool ok = !(fabsf(det) < 1.1920929e-7f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(t < 0.0f);
+        const uint32_t prim = q0.w;
+        const bool better = ok & ((bprim == kMiss) | (t < bt) | ((t == bt) & (prim < bprim)));
+        bt = better ? t : bt; bu = better ? u : bu; bv = better ? v : bv; bprim = better ? prim : bprim;
+    }
+    // a one-leaf octree: its whole answer is the contains test on the root cube (trace_wave; the flag is only ever set with the reference-default semantics)
+    if (sc.oct_single_leaf && bprim != kMiss &&
+        !cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]), add3(o, vscale(d, bt)))) bprim = kMiss;
+    return tested;
+}
+
 template <bool COUNT, bool CONFIRM>
 __global__ __launch_bounds__(kBlock) void raster_kernel(DScene sc, DCamera cam, DPass ps, float4* __restrict__ hits, uint32_t* cursor,
                                                         const uint32_t* __restrict__ film_n, DCounters* counters)
 {
     const int lane = lane_id();
-    const const_u2_ptr tile_ofs = (const_u2_ptr)(uintptr_t)cam.tile_ofs, entries = (const_u2_ptr)(uintptr_t)cam.tile_entries;
-    const const_u4_ptr tris = (const_u4_ptr)(uintptr_t)sc.tris;
     unsigned long long acc_tris = 0;
     PullState pull; uint32_t chunk = 0u;
     while (pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
@@ -593,47 +639,13 @@ __global__ __launch_bounds__(kBlock) void raster_kernel(DScene sc, DCamera cam, 
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             const uint32_t i = i0 + (uint32_t)lane;
             const bool valid = i < n;
-            const uint32_t gi = chunk * ps.chunk + (valid ? i : i0);
-            uint32_t pixel, sampleno; f3 o, d;
-            primary_sample(cam, ps, film_n, gi, pixel, sampleno, o, d);
-            // the tile of these 64 samples (wave-uniform: the host built the bins for exactly this layout)
-            uint32_t s0, p0, first_row, nr, x, y;
-            sample_of(ps, chunk * ps.chunk + i0, s0, p0);
-            pass_column(ps, cam.width, p0, first_row, nr, x, y);
-            const uint32_t tile = bcast_first((pass_row(ps, first_row) / cam.tile_rg) * cam.tile_nblocks + x / cam.tile_cols);
-            const u32x2_t oc = tile_ofs[tile];
-            const float dlen = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z) * 1.00001f;      // t * |d| = distance from the camera; a little long: the early out stays on the safe side
-            float bt = __builtin_inff(), bu = 0.0f, bv = 0.0f; uint32_t bprim = kMiss;
-            for (uint32_t e = 0; e < oc.y; ++e) {
-                const u32x2_t en = entries[oc.x + e];
-                // nothing from here on is nearer than en.y (the list is sorted): done when every lane's hit is nearer still
-                if (__ballot(valid && !(bt * dlen < __uint_as_float(en.y))) == 0ull) break;
-                const uint32_t ti = en.x * 3u;
-                const u32x4_t q0 = tris[ti], q1 = tris[ti + 1u], q2 = tris[ti + 2u];
-                const f3 v0 = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-                const f3 v0v1 = mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)), v0v2 = mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
-                // Moller-Trumbore "late out", intersect.rs:62-98, same operation order (leaf_pred)
-                const f3 pvec = cross3(d, v0v2);
-                const float det = dot3(v0v1, pvec);
-                const float inv_det = div_rn(1.0f, det);
-                const f3 tvec = sub3(o, v0);
-                const float u = dot3(tvec, pvec) * inv_det;
-                const f3 qvec = cross3(tvec, v0v1);
-                const float v = dot3(d, qvec) * inv_det;
-                const float t = dot3(v0v2, qvec) * inv_det;
-                const bool ok = !(fabsf(det) < 1.1920929e-7f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(t < 0.0f);
-                const uint32_t prim = q0.w;
-                const bool better = ok & ((bprim == kMiss) | (t < bt) | ((t == bt) & (prim < bprim)));
-                bt = better ? t : bt; bu = better ? u : bu; bv = better ? v : bv; bprim = better ? prim : bprim;
-            }
-            if (COUNT) acc_tris += (unsigned long long)oc.y * (unsigned long long)__popcll(__ballot(valid));
+            f3 o, d; float bt, bu, bv; uint32_t bprim;
+            const uint32_t tested = raster_tile(sc, cam, ps, film_n, chunk, i0, valid, o, d, bt, bu, bv, bprim);
+            if (COUNT) acc_tris += (unsigned long long)tested * (unsigned long long)__popcll(__ballot(valid));
             if (valid) {
                 const uint32_t rec = chunk * ps.region + i;
-                bool hit = bprim != kMiss;
-                if (CONFIRM && sc.oct_single_leaf && hit)       // a one-leaf octree: its whole answer is the contains test on the root cube (trace_wave)
-                    hit = cube_contains(mk3(sc.oct_root[0], sc.oct_root[1], sc.oct_root[2]), mk3(sc.oct_root[3], sc.oct_root[4], sc.oct_root[5]), add3(o, vscale(d, bt)));
-                st1<1>((uint32_t*)((char*)ps.hit_prim + ((size_t)rec << 2)), hit ? bprim : kMiss);
-                if (hit) st4<1>((float4*)((char*)hits + ((size_t)rec << 4)), make_float4(bt, bu, bv, __uint_as_float(bprim)));
+                st1<1>((uint32_t*)((char*)ps.hit_prim + ((size_t)rec << 2)), bprim);
+                if (bprim != kMiss) st4<1>((float4*)((char*)hits + ((size_t)rec << 4)), make_float4(bt, bu, bv, __uint_as_float(bprim)));
             }
         }
     }
@@ -863,14 +875,17 @@ __device__ __forceinline__ bool light_proves_unoccluded(const DScene& sc, uint32
 // WALK (primary round of the wavefront kernels, reference-default semantics): the octree confirm step of the hits is done
 // here, on the ray this kernel regenerates anyway, instead of in a confirm launch of its own; a hit the octree drops keeps
 // its (zeroed) light-term slot and is shaded no further: it resolves to black like a miss (mod.rs:99-100).
-template <bool PRIMARY, class List, bool WALK = false>
+// RASTER (primary round of the wavefront kernels, tile bins built): the closest hits of the chunk's primary rays are found right here (raster_tile) and
+// handed to the shading loop through LDS (lds_hits: one float4 per sample of a chunk) — no primary trace launch, no hit flags and no hit records in HBM.
+template <bool PRIMARY, class List, bool WALK = false, bool RASTER = false>
 __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level, uint32_t chunk, const List list,
                                             const float4* __restrict__ in_q, uint32_t in_nrad, uint32_t& out_nrad, uint32_t& out_nshadow,
                                             const float4* __restrict__ hits,
                                             float4* __restrict__ out_q, uint2* __restrict__ out_counts,
                                             float* __restrict__ slot_L, uint32_t* __restrict__ sample_slot,
                                             const uint32_t* __restrict__ film_n, DCounters* counters,
-                                            unsigned long long& acc_bounce, unsigned long long& acc_shadow, unsigned long long& acc_hits)
+                                            unsigned long long& acc_bounce, unsigned long long& acc_shadow, unsigned long long& acc_hits,
+                                            float4* lds_hits = nullptr, unsigned long long* acc_tris = nullptr)
 {
     const int lane = lane_id();
     {
@@ -886,10 +901,19 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
         uint32_t cnt = 0u;
         for (uint32_t it = 0; it < n_rad; it += 64u) {
             const uint32_t i = it + (uint32_t)lane;
-            const bool valid = i < n_rad && ld1<2>(&ps.hit_prim[base + i]) != kMiss;
+            bool valid;
+            float4 found = make_float4(0, 0, 0, 0);
+            if (RASTER) {
+                f3 ro, rd; float bt, bu, bv; uint32_t bprim;
+                const uint32_t tested = raster_tile(sc, cam, ps, film_n, chunk, it, i < n_rad, ro, rd, bt, bu, bv, bprim);
+                if (acc_tris) *acc_tris += (unsigned long long)tested * (unsigned long long)__popcll(__ballot(i < n_rad));
+                valid = i < n_rad && bprim != kMiss;
+                found = make_float4(bt, bu, bv, __uint_as_float(bprim));
+            } else valid = i < n_rad && ld1<2>(&ps.hit_prim[base + i]) != kMiss;
             uint32_t n_new;
             const uint32_t pos = wave_append(valid, cnt, n_new);
             if (valid) list[pos] = i;
+            if (RASTER && valid) lds_hits[pos] = found;
             // primary round: light-term slots are handed out per chunk to the samples that hit something
             // (74 % of the primary samples miss and need neither a slot nor zero-filling)
             if (PRIMARY && i < n_rad) st1<2>(&sample_slot[chunk * ps.chunk + i], valid ? chunk * ps.chunk + pos : kMiss);
@@ -922,7 +946,7 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
             float4 h = make_float4(0, 0, 0, 0);
             if (active) {
                 const uint32_t i = list[j + (uint32_t)lane];
-                h = ld4<2>(&hits[base + i]);
+                h = RASTER ? lds_hits[j + (uint32_t)lane] : ld4<2>(&hits[base + i]);
                 if (PRIMARY) {
                     slot = chunk * ps.chunk + j + (uint32_t)lane;       // == sample_slot[chunk * ps.chunk + i]
                     primary_sample(cam, ps, film_n, chunk * ps.chunk + i, pixel, sampleno, o, d);
@@ -1089,7 +1113,7 @@ __device__ __forceinline__ void flush_shade_counters(DCounters* counters, uint32
     }
 }
 
-template <bool PRIMARY, bool WALK>
+template <bool PRIMARY, bool WALK, bool RASTER = false>
 __global__ __launch_bounds__(kBlock, PRIMARY ? (WALK ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : (WALK ? MI355RT_SHADE_SW_BLOCKS : MI355RT_SHADE_S_BLOCKS)) void shade_kernel(DScene sc, DCamera cam, DPass ps, uint32_t level,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       const float4* __restrict__ hits,
@@ -1097,15 +1121,17 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? (WALK ? MI355RT_SHADE_PW_BLOCKS :
                                                       float* __restrict__ slot_L, uint32_t* __restrict__ sample_slot,
                                                       const uint32_t* __restrict__ film_n, DCounters* counters)
 {
-    extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.list_cap hit indices
+    extern __shared__ uint32_t s_list[];             // kWavesPerBlock lists of ps.list_cap hit indices (+ RASTER: kWavesPerBlock x ps.chunk hit records of 16 B)
     const LinearList list{ &s_list[(threadIdx.x >> 6) * ps.list_cap] };
+    float4* lds_hits = RASTER ? (float4*)&s_list[kWavesPerBlock * ps.list_cap] + (threadIdx.x >> 6) * ps.chunk : nullptr;
     const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0;
+    unsigned long long acc_bounce = 0, acc_shadow = 0, acc_hits = 0, acc_tris = 0;
     // chunks are pulled from the round's cursors: the hits sit in a part of the image, culled / empty chunks cost nothing
     PullState pull; uint32_t chunk = 0u;
     while (pull_chunk(cursor, ps.nchunks, kShadePullMode ? kShadePullMode : ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk, 0u, 0u, PRIMARY ? LiveLists() : live_lists(ps))) {
         uint32_t o_rad, o_sh;
-        shade_chunk<PRIMARY, LinearList, WALK>(sc, cam, ps, level, chunk, list, in_q, PRIMARY ? 0u : in_counts[chunk].x, o_rad, o_sh, hits, out_q, out_counts, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits);
+        shade_chunk<PRIMARY, LinearList, WALK, RASTER>(sc, cam, ps, level, chunk, list, in_q, PRIMARY ? 0u : in_counts[chunk].x, o_rad, o_sh, hits, out_q, out_counts, slot_L, sample_slot, film_n, counters, acc_bounce, acc_shadow, acc_hits,
+                                                       lds_hits, (RASTER && (ps.flags & 2u)) ? &acc_tris : nullptr);      // flags & 2: MI355RT_FLAG_COUNT_STEPS
         // a chunk that leaves the primary round with rays goes on the live list of its cursor: the later launches of the pass visit only those (DPass::live)
         if (PRIMARY && kLiveListsOk && ps.live != nullptr && (o_rad | o_sh) != 0u && lane_id() == 0) {
             const uint32_t k = chunk % ps.ncursors;
@@ -1114,6 +1140,7 @@ __global__ __launch_bounds__(kBlock, PRIMARY ? (WALK ? MI355RT_SHADE_PW_BLOCKS :
         }
     }
     flush_shade_counters(counters, wave, acc_bounce, acc_shadow, PRIMARY ? acc_hits : 0ull);
+    if (RASTER && acc_tris && lane_id() == 0) atomicAdd(&counters[wave % kShards].tris_tested, acc_tris);
 }
 
 // ---- resolve: radiance tree -> sample colour -> film ------------------------------------------
@@ -1504,16 +1531,19 @@ hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, co
 
 hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
                         const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts, uint32_t* cursor,
-                        float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters)
+                        float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters, bool raster)
 {
-    const size_t lds = (size_t)ps.list_cap * kWavesPerBlock * sizeof(uint32_t);
+    // raster (primary round only): the kernel finds the primary rays' closest hits itself, through the tile bins (cam.tile_ofs), and keeps them in LDS
+    const size_t lds = (size_t)ps.list_cap * kWavesPerBlock * sizeof(uint32_t) + (raster ? (size_t)ps.chunk * kWavesPerBlock * sizeof(float4) : 0);
     unsigned blocks = (ps.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned cap = (unsigned)num_cus * (primary ? (walk ? MI355RT_SHADE_PW_BLOCKS : MI355RT_SHADE_P_BLOCKS) : (walk ? MI355RT_SHADE_SW_BLOCKS : MI355RT_SHADE_S_BLOCKS));    // what the chip holds at once
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(kBlock);
 #define MI355RT_SHADE_ARGS grid, block, lds, stream, sc, cam, ps, level, (const float4*)in_q, (const uint2*)in_counts, (const float4*)hits, (float4*)out_q, (uint2*)out_counts, cursor, slot_L, sample_slot, film_n, counters
-    if (primary && walk) hipLaunchKernelGGL((shade_kernel<true, true>), MI355RT_SHADE_ARGS);
+    if (primary && raster && walk) hipLaunchKernelGGL((shade_kernel<true, true, true>), MI355RT_SHADE_ARGS);
+    else if (primary && raster) hipLaunchKernelGGL((shade_kernel<true, false, true>), MI355RT_SHADE_ARGS);
+    else if (primary && walk) hipLaunchKernelGGL((shade_kernel<true, true>), MI355RT_SHADE_ARGS);
     else if (primary) hipLaunchKernelGGL((shade_kernel<true, false>), MI355RT_SHADE_ARGS);
     else if (walk) hipLaunchKernelGGL((shade_kernel<false, true>), MI355RT_SHADE_ARGS);
     else hipLaunchKernelGGL((shade_kernel<false, false>), MI355RT_SHADE_ARGS);

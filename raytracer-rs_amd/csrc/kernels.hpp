@@ -16,7 +16,7 @@ hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, co
                                const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n);
 hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,
                         const void* in_q, const void* in_counts, const void* hits, void* out_q, void* out_counts, uint32_t* cursor,
-                        float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters);
+                        float* slot_L, uint32_t* sample_slot, const uint32_t* film_n, DCounters* counters, bool raster = false);   // raster: primary round, hits through the tile bins inside the launch
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color, uint32_t* ctrl);   // ctrl != null: zero the pass's work cursors on the way out
 // one 50-row frame (1 sample per pixel) in a single launch: every wave takes a 64-sample chunk through all rounds

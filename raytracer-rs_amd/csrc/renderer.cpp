@@ -781,6 +781,15 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
     hipStream_t tst = trace_stream ? trace_stream : st;
     const bool count = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0;
     const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
+    // Primary round with tile bins: the shade launch finds the closest hits itself (kernels.hip, shade_chunk<RASTER>) — no trace launch at all —
+    // whenever that launch also does what else the round needs (the octree confirm step of its hits, or nothing to confirm).
+    const bool confirm_round = mode_ == kModeConfirm && !dscene_.oct_single_leaf;
+    const char* sw_env = getenv("MI355RT_SHADE_WALK");
+    const bool fuse_primary = r == 0 && cam.tile_ofs != nullptr && mode_ != kModeOctreeWalk && (!confirm_round || !sw_env || atoi(sw_env) >= 1) && !getenv("MI355RT_NO_FUSE_PRIMARY");
+    const void* in_q = r == 0 ? nullptr : sl.d_queue[(r - 1) & 1];
+    const void* in_c = r == 0 ? nullptr : sl.d_chunk_counts[(r - 1) & 1];
+    const bool balance_dbg = !fuse_primary && count && getenv("MI355RT_DEBUG_UTIL") && mode_ != kModeOctreeWalk;
+    if (!fuse_primary) {
     if (tst != st) { HIP_TRY(hipEventRecord(sl.ev_ready, st)); HIP_TRY(hipStreamWaitEvent(tst, sl.ev_ready, 0)); }
     if (timed) {
         if (ev_used_ + 2 > ev_pool_.size()) {
@@ -789,9 +798,6 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
         HIP_TRY(hipEventRecord(ev_pool_[ev_used_], tst));
         ev_secondary_.resize(ev_pool_.size() / 2); ev_secondary_[ev_used_ / 2] = r > 0;
     }
-    const void* in_q = r == 0 ? nullptr : sl.d_queue[(r - 1) & 1];
-    const void* in_c = r == 0 ? nullptr : sl.d_chunk_counts[(r - 1) & 1];
-    const bool balance_dbg = count && getenv("MI355RT_DEBUG_UTIL") && mode_ != kModeOctreeWalk;
     if (balance_dbg) {       // load-balance diagnostics of this launch (debug only: synchronises)
         DCounters init{};
         HIP_TRY(hipMemcpy(&init, d_counters_, sizeof init, hipMemcpyDeviceToHost));
@@ -811,6 +817,7 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
     if (timed) { HIP_TRY(hipEventRecord(ev_pool_[ev_used_ + 1], tst)); ev_used_ += 2; }
     ++launches_;
     if (tst != st) { HIP_TRY(hipEventRecord(sl.ev_traced, tst)); HIP_TRY(hipStreamWaitEvent(st, sl.ev_traced, 0)); }
+    }
     // true closest hits -> the reference intersector's answers; settles the shadow rays of this round.  One-leaf octrees: done in the
     // trace kernel.  Radiance hits: confirmed by the round's SHADE kernel, which loads the ray and the hit record anyway (primary
     // round: no confirm launch at all; secondary rounds: the confirm launch handles the shadow records only).  24.3 -> 23.3 ms per frame.
@@ -844,7 +851,7 @@ bool Renderer::pass_round(PassRun& run, uint32_t r, hipStream_t trace_stream, in
                     (double)c0.t_sum_end / c0.n_waves / 100.0, (double)(c0.t_first_end - c0.t_start) / 100.0, (double)(c0.t_last_end - c0.t_start) / 100.0);
     }
     if (r <= cfg.recursions)
-        HIP_TRY(launch_shade(st, num_cus_, r == 0, shade_walks, dscene_, cam, ps, r, in_q, in_c, sl.d_hits, sl.d_queue[r & 1], sl.d_chunk_counts[r & 1], sl.d_ctrl + r * kCtrlWordsPerRound + kShadeCursorOffset, sl.d_slot_L, sl.d_sample_slot, d_film_n_, d_counters_));
+        HIP_TRY(launch_shade(st, num_cus_, r == 0, shade_walks, dscene_, cam, ps, r, in_q, in_c, sl.d_hits, sl.d_queue[r & 1], sl.d_chunk_counts[r & 1], sl.d_ctrl + r * kCtrlWordsPerRound + kShadeCursorOffset, sl.d_slot_L, sl.d_sample_slot, d_film_n_, d_counters_, fuse_primary));
     return true;
 }
 
