@@ -708,8 +708,10 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     ps.rows = d_rows; ps.row0 = row0; ps.row_wrap = row_wrap; ps.npix = npix; ps.nsamples = (uint32_t)nsamples;
     ps.spp = npix ? (uint32_t)(nsamples / npix) : 1u;
     // samples of a pixel kept together in the pass order (kernels.hip, sample_of): 2 — thai2 frame 21.1 / 20.7 / 20.7 / 20.9 / 21.5 / 21.6 ms at
-    // 1 / 2 / 4 / 8 / 16 / 64, one rank's share of eight 3.27 / 3.24 / 3.30 / 3.34 / 3.40 / 3.63 ms (profiles/r03_notes.md); the largest divisor of spp <= the wish
-    uint32_t group = 2u;
+    // 1 / 2 / 4 / 8 / 16 / 64, one rank's share of eight 3.27 / 3.24 / 3.30 / 3.34 / 3.40 / 3.63 ms (profiles/r03_notes.md); the largest divisor of spp <= the wish.
+    // With the primary rays going through the tile bins (a wave's tile is 64 / group pixels: shorter lists for smaller tiles) and most shadow rays
+    // never made: 15.5 / 15.4 / 15.1 / 15.5 ms at 2 / 4 / 8 / 16 — 8 since.
+    uint32_t group = 8u;
     if (const char* e = getenv("MI355RT_SAMPLE_GROUP")) { int v = atoi(e); if (v >= 1) group = (uint32_t)v; }
     group = std::max(1u, std::min(group, ps.spp));
     while (ps.spp % group) --group;
