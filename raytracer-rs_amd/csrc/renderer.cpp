@@ -397,7 +397,7 @@ void Renderer::collect_cull_boxes()
 // projected into the camera's (dir_x, dir_y) plane; the cells their bounding rectangle touches are set.  Any primary ray that hits a triangle has
 // its (dir_x, dir_y) inside that triangle's rectangle, so a chunk footprint that touches no set cell holds only misses.  Rebuilt (and uploaded,
 // with the renderer's streams idle) only when the camera changed; scenes of more than 2 M triangles keep the first stage only.
-bool Renderer::refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin)
+bool Renderer::refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin, bool build)
 {
     c.cull_mask = nullptr; c.mask_x0 = c.mask_y0 = 0.0f; c.mask_inv_cx = c.mask_inv_cy = 0.0f;
     if (c.cull_valid == 0 || bvh.tris.empty() || bvh.tris.size() > (2u << 20) || getenv("MI355RT_NO_CULL_MASK")) return true;
@@ -407,6 +407,9 @@ bool Renderer::refresh_cull_mask(DCamera& c, const double inv[3][3], double pad,
         if (mask_valid_) { c.cull_mask = d_cull_mask_; c.mask_x0 = mask_dom_[0]; c.mask_y0 = mask_dom_[1]; c.mask_inv_cx = mask_dom_[2]; c.mask_inv_cy = mask_dom_[3]; }
         return true;
     }
+    // A 50-row frame of the drop-in loop (0.3 ms) is not worth a rebuild (1.5 ms) when the camera has just moved — the reference's loop moves it between
+    // any two calls while a key is held, main.rs:116-169: such calls cull with the first stage alone until a whole-frame pass builds the mask
+    if (!build) return true;
     mask_key_ = key; mask_valid_ = false;
     // domain: the bounding rectangle of the first stage's rectangles (everything outside is empty by the first stage)
     double X0 = 1e300, X1 = -1e300, Y0 = 1e300, Y1 = -1e300;
@@ -612,7 +615,7 @@ DCamera Renderer::device_camera(const DPass* layout, const std::vector<uint32_t>
             if (front) c.cull_valid = n;         // a box behind / around the camera: no culling at all
             // the mask pads every vertex by ten times what the BVH pads its boxes with (bvh.cpp: 2e-5 of the diagonal) — the same assumption about
             // the triangle test's rounding that the traversal itself rests on, with a wider margin
-            if (front) (void)refresh_cull_mask(c, inv, 2e-4 * std::sqrt(diag) + 1e-7, 1e-6 * std::sqrt(diag));
+            if (front) (void)refresh_cull_mask(c, inv, 2e-4 * std::sqrt(diag) + 1e-7, 1e-6 * std::sqrt(diag), layout != nullptr);
             if (front && layout && rows) (void)refresh_tile_bins(c, inv, 2e-4 * std::sqrt(diag) + 1e-7, 1e-6 * std::sqrt(diag), *layout, *rows);
             if (getenv("MI355RT_DEBUG_CULL")) { fprintf(stderr, "[mi355rt] cull rects %u front %d max_x %g\n", n, (int)front, c.max_x); for (uint32_t k = 0; k < n; ++k) fprintf(stderr, "   x [%g, %g] y [%g, %g]\n", c.cull_rect[k][0], c.cull_rect[k][1], c.cull_rect[k][2], c.cull_rect[k][3]); }
         }

@@ -135,7 +135,7 @@ private:
     // layout + rows: the pass whose primary rays the tile bins are for and the (host copy of the) row list it walks (null: no bins needed)
     DCamera device_camera(const DPass* layout = nullptr, const std::vector<uint32_t>* rows = nullptr);
     bool refresh_tile_bins(DCamera& c, const double inv[3][3], double pad, double zmin, const DPass& ps, const std::vector<uint32_t>& rows);
-    bool refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin);
+    bool refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin, bool build);
     void collect_cull_boxes();
     void build_sample_table(std::vector<float>& table4);
     template <class T> bool upload(T*& dptr, const void* src, size_t bytes);
