@@ -397,6 +397,40 @@ void Renderer::collect_cull_boxes()
 // projected into the camera's (dir_x, dir_y) plane; the cells their bounding rectangle touches are set.  Any primary ray that hits a triangle has
 // its (dir_x, dir_y) inside that triangle's rectangle, so a chunk footprint that touches no set cell holds only misses.  Rebuilt (and uploaded,
 // with the renderer's streams idle) only when the camera changed; scenes of more than 2 M triangles keep the first stage only.
+// The screen rectangle of every triangle (BVH order) in the camera's (dir_x, dir_y) plane, with every vertex padded by `pad` in world space: what the
+// coverage mask and the tile bins are made of.  A point p maps to v = (p - origin) * inv, (dir_x, dir_y) = (v.x, -v.y) / v.z; moving p by at most pad
+// per axis moves v.x by at most pad * kx (kx = the absolute column sum of inv), so dir_x by at most pad * (kx + |dir_x| kz) / (v.z - pad kz): the
+// rectangle of the three projected vertices, widened by that, holds the projection of the whole padded triangle.  false: something is not in front.
+// Cached per camera (both consumers are rebuilt when it changes).
+bool Renderer::project_triangles(const DCamera& c, const double inv[3][3], double pad, double zmin)
+{
+    std::vector<float> key(c.rot, c.rot + 16);
+    key.insert(key.end(), c.origin, c.origin + 3);
+    if (key == rects_key_ && tri_rects_.size() == bvh.tris.size()) return rects_ok_;
+    rects_key_ = key; rects_ok_ = false;
+    tri_rects_.resize(bvh.tris.size());
+    const double kx = std::fabs(inv[0][0]) + std::fabs(inv[1][0]) + std::fabs(inv[2][0]), ky = std::fabs(inv[0][1]) + std::fabs(inv[1][1]) + std::fabs(inv[2][1]);
+    const double kz = std::fabs(inv[0][2]) + std::fabs(inv[1][2]) + std::fabs(inv[2][2]);
+    for (size_t i = 0; i < bvh.tris.size(); ++i) {
+        const BvhTri& t = bvh.tris[i];
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int v = 0; v < 3; ++v) {
+            double w[3];
+            for (int a = 0; a < 3; ++a) w[a] = (double)t.v0[a] + (v == 1 ? (double)t.e1[a] : v == 2 ? (double)t.e2[a] : 0.0) - c.origin[a];
+            const double vx = w[0] * inv[0][0] + w[1] * inv[1][0] + w[2] * inv[2][0];
+            const double vy = w[0] * inv[0][1] + w[1] * inv[1][1] + w[2] * inv[2][1];
+            const double vz = w[0] * inv[0][2] + w[1] * inv[1][2] + w[2] * inv[2][2] - pad * kz;       // the nearest the padded vertex can be
+            if (!(vz > zmin)) return false;
+            const double dx = vx / (vz + pad * kz), dy = -vy / (vz + pad * kz);
+            const double mx = pad * (kx + std::fabs(dx) * kz) / vz * 1.0001 + 4e-16 * (1.0 + std::fabs(dx)), my = pad * (ky + std::fabs(dy) * kz) / vz * 1.0001 + 4e-16 * (1.0 + std::fabs(dy));
+            x0 = std::min(x0, dx - mx); x1 = std::max(x1, dx + mx); y0 = std::min(y0, dy - my); y1 = std::max(y1, dy + my);
+        }
+        tri_rects_[i] = TriRect{ x0, x1, y0, y1 };
+    }
+    rects_ok_ = true;
+    return true;
+}
+
 bool Renderer::refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin, bool build)
 {
     c.cull_mask = nullptr; c.mask_x0 = c.mask_y0 = 0.0f; c.mask_inv_cx = c.mask_inv_cy = 0.0f;
@@ -418,22 +452,9 @@ bool Renderer::refresh_cull_mask(DCamera& c, const double inv[3][3], double pad,
     const double icx = kCullGrid / (X1 - X0), icy = kCullGrid / (Y1 - Y0);
     constexpr uint32_t wpr = kCullGrid / 32u;
     std::vector<uint32_t> bits((size_t)kCullGrid * wpr, 0u);
-    for (const BvhTri& t : bvh.tris) {
-        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-        for (int v = 0; v < 3; ++v) {
-            const double p[3] = { (double)t.v0[0] + (v == 1 ? t.e1[0] : v == 2 ? t.e2[0] : 0.0f), (double)t.v0[1] + (v == 1 ? t.e1[1] : v == 2 ? t.e2[1] : 0.0f),
-                                  (double)t.v0[2] + (v == 1 ? t.e1[2] : v == 2 ? t.e2[2] : 0.0f) };
-            for (int k = 0; k < 8; ++k) {          // the vertex's padded cube
-                double w[3];
-                for (int a = 0; a < 3; ++a) w[a] = p[a] + ((k >> a) & 1 ? pad : -pad) - c.origin[a];
-                const double vx = w[0] * inv[0][0] + w[1] * inv[1][0] + w[2] * inv[2][0];
-                const double vy = w[0] * inv[0][1] + w[1] * inv[1][1] + w[2] * inv[2][1];
-                const double vz = w[0] * inv[0][2] + w[1] * inv[1][2] + w[2] * inv[2][2];
-                if (!(vz > zmin)) return true;                          // cannot happen behind a valid first stage; no mask then
-                const double dx = vx / vz, dy = -vy / vz;
-                x0 = std::min(x0, dx); x1 = std::max(x1, dx); y0 = std::min(y0, dy); y1 = std::max(y1, dy);
-            }
-        }
+    if (!project_triangles(c, inv, pad, zmin)) return true;            // cannot happen behind a valid first stage; no mask then
+    for (const TriRect& tr : tri_rects_) {
+        const double x0 = tr.x0, x1 = tr.x1, y0 = tr.y0, y1 = tr.y1;
         const double mx = 1e-4 * (x1 - x0) + 1e-6, my = 1e-4 * (y1 - y0) + 1e-6;
         // 1/100 of a cell of slack: the kernel computes its cell indices in f32 (error < 1e-4 cells for |dir| of a few units)
         const long i0 = std::max(0L, (long)std::floor((x0 - mx - X0) * icx - 0.01)), i1 = std::min((long)kCullGrid - 1, (long)std::floor((x1 + mx - X0) * icx + 0.01));
@@ -489,21 +510,12 @@ bool Renderer::refresh_tile_bins(DCamera& c, const double inv[3][3], double pad,
     std::vector<Ref> refs;
     refs.reserve(bvh.tris.size() * 6);
     const double org[3] = { c.origin[0], c.origin[1], c.origin[2] };
+    if (!project_triangles(c, inv, pad, zmin)) BINS_OUT(7);
     for (size_t k = 0; k < bvh.tris.size(); ++k) {
         const BvhTri& t = bvh.tris[k];
         float v9[9];
         for (int a = 0; a < 3; ++a) { v9[a] = t.v0[a]; v9[3 + a] = t.v0[a] + t.e1[a]; v9[6 + a] = t.v0[a] + t.e2[a]; }
-        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-        for (int v = 0; v < 3; ++v) for (int q = 0; q < 8; ++q) {          // the vertices' padded cubes, as in the culling mask
-            double w[3];
-            for (int a = 0; a < 3; ++a) w[a] = (double)v9[3 * v + a] + ((q >> a) & 1 ? pad : -pad) - org[a];
-            const double vx = w[0] * inv[0][0] + w[1] * inv[1][0] + w[2] * inv[2][0];
-            const double vy = w[0] * inv[0][1] + w[1] * inv[1][1] + w[2] * inv[2][1];
-            const double vz = w[0] * inv[0][2] + w[1] * inv[1][2] + w[2] * inv[2][2];
-            if (!(vz > zmin)) BINS_OUT(7);
-            const double dx = vx / vz, dy = -vy / vz;
-            x0 = std::min(x0, dx); x1 = std::max(x1, dx); y0 = std::min(y0, dy); y1 = std::max(y1, dy);
-        }
+        const double x0 = tri_rects_[k].x0, x1 = tri_rects_[k].x1, y0 = tri_rects_[k].y0, y1 = tri_rects_[k].y1;     // the padded screen rectangle, as in the culling mask
         const double ex = 1e-4 * (x1 - x0) + 1e-6, ey = 1e-4 * (y1 - y0) + 1e-6;
         // columns cu and row indices cv (kernels.hip, primary_sample) whose jitter range [cu, cu + 1) / W, [cv, cv + 1) / H can reach the rectangle;
         // 1/100 of a column of slack covers the f32 rounding of the kernel's own expressions

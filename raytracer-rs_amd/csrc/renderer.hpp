@@ -136,6 +136,11 @@ private:
     DCamera device_camera(const DPass* layout = nullptr, const std::vector<uint32_t>* rows = nullptr);
     bool refresh_tile_bins(DCamera& c, const double inv[3][3], double pad, double zmin, const DPass& ps, const std::vector<uint32_t>& rows);
     bool refresh_cull_mask(DCamera& c, const double inv[3][3], double pad, double zmin, bool build);
+    bool project_triangles(const DCamera& c, const double inv[3][3], double pad, double zmin);
+    struct TriRect { double x0, x1, y0, y1; };
+    std::vector<TriRect> tri_rects_;     // padded screen rectangles of the triangles (BVH order) for the camera of rects_key_
+    std::vector<float> rects_key_;
+    bool rects_ok_ = false;
     void collect_cull_boxes();
     void build_sample_table(std::vector<float>& table4);
     template <class T> bool upload(T*& dptr, const void* src, size_t bytes);
