@@ -75,7 +75,10 @@ constexpr uint32_t kShadePullMode = MI355RT_SHADE_PULL;
 #endif
 constexpr uint32_t kConfirmPullMode = MI355RT_CONFIRM_PULL;
 constexpr bool kFusedFenceAgent = MI355RT_FUSED_FENCE_AGENT != 0;      // A/B knob of the build (see phase_fence)
-constexpr int kInnerStepsPerIteration = 2;     // measured: 1 -> 2 takes 9 % off the trace kernel, 3 and 4 add nothing
+#ifndef MI355RT_INNER_STEPS
+#define MI355RT_INNER_STEPS 2
+#endif
+constexpr int kInnerStepsPerIteration = MI355RT_INNER_STEPS;     // measured: 1 -> 2 takes 9 % off the trace kernel, 3 and 4 add nothing
 
 // One device word sustains only ~88 atomics/us on this chip: the statistics counters that every wave
 // flushes into exist in kShards copies (the host adds them up), and the work cursor is touched

@@ -15,6 +15,8 @@ def bits(a):
 def one_case(pkg, O, scenes, rng, verbose=True):
     name = rng.choice(["ico2", "4boxes", "ico3_tex", "thai2"], p=[0.35, 0.2, 0.2, 0.25])
     w, h = int(rng.integers(4, 161)), int(rng.integers(3, 121))
+    if rng.random() < 0.4:                              # sizes whose wave tiles do not straddle row groups: the tile bins of the primary rays engage
+        w, h = 8 * int(rng.integers(1, 21)), 8 * int(rng.integers(1, 16))
     seed = int(rng.integers(0, 2**31))
     rec, spread = [(2, 1), (2, 1), (1, 2), (3, 1), (0, 1), (1, 1), (2, 2)][int(rng.integers(0, 7))]
     tpl = int(rng.choice([1, 5, 20, 70, 100]))
@@ -25,6 +27,13 @@ def one_case(pkg, O, scenes, rng, verbose=True):
     if rng.random() < 0.3:
         world = int(rng.integers(2, 5)); stripes = dict(stripe_rows=int(rng.choice([1, 2, 4, 8])), stripe_rank=int(rng.integers(0, world)), stripe_world=world)
     sc = scenes(name)
+    if rng.random() < 0.35:                             # the light somewhere else: in, on or around the geometry (the lights' depth maps, the ray's tail behind the light)
+        sc = dict(sc); sc["lights"] = sc["lights"].copy()
+        v = sc["tri_verts"].reshape(-1, 3); lo, hi = v.min(0), v.max(0)
+        kind = rng.random()
+        if kind < 0.4: sc["lights"][0, :3] = rng.uniform(lo, hi)
+        elif kind < 0.7: sc["lights"][0, :3] = v[int(rng.integers(0, len(v)))] + rng.normal(0, 1e-3, 3)
+        else: sc["lights"][0, :3] = rng.uniform(lo - 2 * (hi - lo), hi + 2 * (hi - lo))
     rt = pkg.create_raytracer_from_arrays(sc, tpl, w, h, seed=seed, recursions=rec, spread=spread, flags=gflags, **stripes)
     orc = O.Oracle(sc, w, h, tris_per_leaf=tpl, recursions=rec, spread=spread, seed=seed, flags=oflags)
     desc = "%s %dx%d seed %d rec %d spread %d tpl %d sem %d %s" % (name, w, h, seed, rec, spread, tpl, sem, stripes or "")
