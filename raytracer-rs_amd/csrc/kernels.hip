@@ -1593,6 +1593,34 @@ __global__ __launch_bounds__(256) void film_clear_rows_kernel(const uint32_t* __
     film_sumsq[3 * pixel] = 0.0f; film_sumsq[3 * pixel + 1] = 0.0f; film_sumsq[3 * pixel + 2] = 0.0f;
     film_n[pixel] = 0u;
 }
+// copy the film entries of `total` rows of the owned-row list (entries first, first + 1, ... cyclically) to a packed backup, or back
+// (Renderer::trace_frame_additive: the rows a speculatively launched 50-row frame is about to change)
+__global__ __launch_bounds__(256) void film_rows_copy_kernel(const uint32_t* __restrict__ rows, uint32_t first, uint32_t total, uint32_t nown, uint32_t width,
+                                                            float* film_sum, float* film_sumsq, uint32_t* film_n, float* bk_sum, float* bk_sumsq, uint32_t* bk_n, int restore)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)total * width) return;
+    const uint32_t k = (uint32_t)(i / width), x = (uint32_t)(i % width);
+    const size_t pixel = (size_t)rows[(first + k) % nown] * width + x;
+    if (restore) {
+        film_sum[3 * pixel] = bk_sum[3 * i]; film_sum[3 * pixel + 1] = bk_sum[3 * i + 1]; film_sum[3 * pixel + 2] = bk_sum[3 * i + 2];
+        film_sumsq[3 * pixel] = bk_sumsq[3 * i]; film_sumsq[3 * pixel + 1] = bk_sumsq[3 * i + 1]; film_sumsq[3 * pixel + 2] = bk_sumsq[3 * i + 2];
+        film_n[pixel] = bk_n[i];
+    } else {
+        bk_sum[3 * i] = film_sum[3 * pixel]; bk_sum[3 * i + 1] = film_sum[3 * pixel + 1]; bk_sum[3 * i + 2] = film_sum[3 * pixel + 2];
+        bk_sumsq[3 * i] = film_sumsq[3 * pixel]; bk_sumsq[3 * i + 1] = film_sumsq[3 * pixel + 1]; bk_sumsq[3 * i + 2] = film_sumsq[3 * pixel + 2];
+        bk_n[i] = film_n[pixel];
+    }
+}
+hipError_t launch_film_rows_copy(hipStream_t stream, const uint32_t* rows, uint32_t first, uint32_t total, uint32_t nown, uint32_t width,
+                                 float* film_sum, float* film_sumsq, uint32_t* film_n, float* bk_sum, float* bk_sumsq, uint32_t* bk_n, bool restore)
+{
+    const size_t n = (size_t)total * width;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(film_rows_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rows, first, total, nown, width, film_sum, film_sumsq, film_n, bk_sum, bk_sumsq, bk_n, restore ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_film_clear_rows(hipStream_t stream, const uint32_t* rows, uint32_t nrows, uint32_t width, float* film_sum, float* film_sumsq, uint32_t* film_n)
 {
     const size_t n = (size_t)nrows * width;

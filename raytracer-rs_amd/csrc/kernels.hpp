@@ -37,6 +37,9 @@ hipError_t launch_place_stripes(hipStream_t stream, const uint32_t* gathered, ui
                                 uint32_t stripe_rows, uint32_t world, uint32_t slot_rows);
 // Film::clear restricted to the listed rows (a striped handle's own rows)
 hipError_t launch_film_clear_rows(hipStream_t stream, const uint32_t* rows, uint32_t nrows, uint32_t width, float* film_sum, float* film_sumsq, uint32_t* film_n);
+// film entries of `total` rows of the owned-row list (cyclic from entry `first`) -> packed backup, or back
+hipError_t launch_film_rows_copy(hipStream_t stream, const uint32_t* rows, uint32_t first, uint32_t total, uint32_t nown, uint32_t width,
+                                 float* film_sum, float* film_sumsq, uint32_t* film_n, float* bk_sum, float* bk_sumsq, uint32_t* bk_n, bool restore);
 hipError_t launch_slab(hipStream_t stream, const float* inv_rays6, const float* cubes6, uint32_t n, uint8_t* hit, float* tmin);
 hipError_t launch_film_stat(hipStream_t stream, bool variances, size_t npix, const float* film_sum, const float* film_sumsq, const uint32_t* film_n, float* out);
 // the gather microbenchmark behind bench.py's roofline: num_cus * 8 blocks walk `steps` random nodes of `table` each

@@ -82,6 +82,7 @@ void Renderer::build_sample_table(std::vector<float>& table4)
 bool Renderer::set_seed(uint64_t seed)
 {
     if (!bind()) return false;
+    if (!settle_speculation()) return false;
     cfg.seed = seed;
     std::vector<float> table4;
     build_sample_table(table4);
@@ -95,6 +96,7 @@ bool Renderer::set_flags(uint32_t flags)
 {
     constexpr uint32_t kCreateMask = MI355RT_FLAG_OCTREE_SEMANTICS | MI355RT_FLAG_TRUE_CLOSEST_HIT | MI355RT_FLAG_GROUP_SHARES_DEVICE | MI355RT_FLAG_DEVICE_LBVH;
     if ((flags ^ cfg.flags) & kCreateMask) { last_error = "the intersector flags (OCTREE_SEMANTICS, TRUE_CLOSEST_HIT) are create-time flags: they cannot be changed with mi355rt_set_flags"; return false; }
+    if (flags != cfg.flags && !settle_speculation()) return false;
     cfg.flags = flags;
     return true;
 }
@@ -286,6 +288,8 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     if (!upload(d_ldr_, nullptr, npix * 4)) return bail();
     ldr_dirty_.assign(cfg.height, (uint8_t)1);
     if (hipEventCreateWithFlags(&ev_tonemap_, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_gather_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
+    if (hipEventCreateWithFlags(&ev_call_done_, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_spec_done_, hipEventDisableTiming) != hipSuccess
+        || hipStreamCreateWithFlags(&read_stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipEventCreate / hipStreamCreate failed"; return false; }
     std::vector<uint32_t> all(cfg.height);
     for (uint32_t r = 0; r < cfg.height; ++r) {
         all[r] = r;
@@ -344,6 +348,10 @@ Renderer::~Renderer()
     comm_destroy();
     if (d_gather_) (void)hipFree(d_gather_);
     if (ev_tonemap_) (void)hipEventDestroy(ev_tonemap_);
+    if (read_stream_) { (void)hipStreamSynchronize(read_stream_); (void)hipStreamDestroy(read_stream_); }
+    if (ev_call_done_) (void)hipEventDestroy(ev_call_done_);
+    if (ev_spec_done_) (void)hipEventDestroy(ev_spec_done_);
+    if (h_counters_spec_) (void)hipHostFree(h_counters_spec_);
     if (ev_gather_) (void)hipEventDestroy(ev_gather_);
     free_pass_buffers();
     for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
@@ -893,6 +901,8 @@ bool Renderer::run_pass(Slice& sl, const uint32_t* d_rows, uint32_t row0, uint32
 bool Renderer::begin_call()
 {
     if (!bind()) return false;
+    if (!settle_speculation()) return false;
+    call_done_valid_ = false;
     ev_used_ = 0; launches_ = 0;
     counts_pending_ = false;
     HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
@@ -972,7 +982,8 @@ bool Renderer::last_counts(mi355rt_ray_counts& out)
 {
     if (counts_pending_) {
         if (!bind()) return false;
-        HIP_TRY(hipStreamSynchronize(stream_));
+        if (call_done_valid_) HIP_TRY(hipEventSynchronize(ev_call_done_));       // a 50-row frame: its kernel and its counters' copy, not what was queued behind them
+        else HIP_TRY(hipStreamSynchronize(stream_));
         counts_pending_ = false;
         const bool timed = pending_timed_; pending_timed_ = false;
         if (!fetch_counts(pending_primary_, timed)) return false;
@@ -1028,35 +1039,91 @@ uint32_t Renderer::trace_frame_additive()
     // fast path: one launch per run, nothing uploaded, nothing waited for
     if (!bind()) return 0;
     ev_used_ = 0; launches_ = 0;
-    if (hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_) != hipSuccess) { last_error = "hipMemsetAsync failed"; return 0; }
-    Slice& sl = slices_[0];
+    const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
     const DCamera cam = device_camera();
-    for (uint32_t done = 0; done < win.total; done += nown) {
-        const uint32_t n = std::min(nown, win.total - done);
-        const size_t nsamples = (size_t)n * cfg.width;
-        if (!ensure_pass_capacity(sl, nsamples)) return 0;
-        DPass ps;
-        uint32_t fchunk = 32u;                                            // samples per wave (a 4x8 pixel tile): 64 / 32 / 16 measure 0.303 / 0.266 / 0.277 ms per launch
-        if (const char* e = getenv("MI355RT_FUSED_CHUNK")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fchunk = (uint32_t)v; }   // <= 64: the LDS lists hold one row per record of a sample; >= kMinChunk: the counts arrays
-        describe_pass(ps, sl, d_owned_rows_, (win.first + done) % nown, nown, (uint32_t)nsamples, nsamples, fchunk, false, 0, 0);
-        if (ps.nchunks > sl.count_entries || (size_t)ps.nchunks * ps.region > sl.queue_records) { last_error = "internal: fused pass does not fit the pass buffers"; return 0; }
-        const bool timed = (cfg.flags & MI355RT_FLAG_TIME_KERNELS) != 0;
-        if (timed) {
-            while (ev_used_ + 2 > ev_pool_.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { last_error = "hipEventCreate failed"; return 0; } ev_pool_.push_back(ev); }
-            (void)hipEventRecord(ev_pool_[ev_used_], stream_);
-            ev_secondary_.resize(ev_pool_.size() / 2); ev_secondary_[ev_used_ / 2] = false;
-        }
-        hipError_t e = launch_fused_pass(stream_, num_cus_, mode_ == kModeConfirm, dscene_, cam, ps, max_level_nodes_, records_per_sample_, sl.d_queue[0], sl.d_queue[1],
-                                         sl.d_hits, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, d_counters_);
-        if (e != hipSuccess) { fail(e, "fused pass launch"); return 0; }
-        if (timed) { (void)hipEventRecord(ev_pool_[ev_used_ + 1], stream_); ev_used_ += 2; }
-        ++launches_;
+    std::vector<float> cam_key(cam.rot, cam.rot + 16);
+    cam_key.insert(cam_key.end(), cam.origin, cam.origin + 3); cam_key.push_back(cam.max_x); cam_key.push_back(cam.max_y);
+    // Was this frame launched already, speculatively, behind the previous one?  Then it is done or under way: take it over.
+    bool adopted = false;
+    if (spec_.valid) {
+        if (spec_.row == current_row && spec_.first == win.first && spec_.total == win.total && spec_.seed == cfg.seed && spec_.flags == cfg.flags && spec_.cam_key == cam_key && !timed) {
+            adopted = true; spec_.valid = false; ++spec_adopted_;
+            std::swap(d_counters_, d_counters_spec_); std::swap(h_counters_, h_counters_spec_); std::swap(ev_call_done_, ev_spec_done_);
+            launches_ = 1;
+        } else if (!settle_speculation()) return 0;
     }
+    if (!adopted) {
+        if (hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_) != hipSuccess) { last_error = "hipMemsetAsync failed"; return 0; }
+        for (uint32_t done = 0; done < win.total; done += nown) {
+            const uint32_t n = std::min(nown, win.total - done);
+            if (timed) {
+                while (ev_used_ + 2 > ev_pool_.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { last_error = "hipEventCreate failed"; return 0; } ev_pool_.push_back(ev); }
+                (void)hipEventRecord(ev_pool_[ev_used_], stream_);
+                ev_secondary_.resize(ev_pool_.size() / 2); ev_secondary_[ev_used_ / 2] = false;
+            }
+            if (!launch_fused_window((win.first + done) % nown, n, cam, d_counters_)) return 0;
+            if (timed) { (void)hipEventRecord(ev_pool_[ev_used_ + 1], stream_); ev_used_ += 2; }
+            ++launches_;
+        }
+        if (!queue_counts_copy()) return 0;
+        if (ev_call_done_ && hipEventRecord(ev_call_done_, stream_) != hipSuccess) { last_error = "hipEventRecord failed"; return 0; }
+    }
+    call_done_valid_ = ev_call_done_ != nullptr;
     current_row = win.next_row;
     mark_dirty_window(win.first, win.total);
-    if (!queue_counts_copy()) return 0;
     counts_pending_ = true; pending_primary_ = (uint64_t)win.total * cfg.width; pending_timed_ = false;
+    // The next frame, speculatively (see renderer.hpp): only in the plain case — the whole image on one device (striped handles and device-group members
+    // read their pixels out through paths that would give every speculation up), one launch per frame, two consecutive windows that share no row,
+    // no instrumentation.
+    static const bool no_spec = getenv("MI355RT_NO_SPECULATE") != nullptr;
+    const FrameWindow nxt = frame_window(current_row, cfg.height, cfg.stripe_rows, cfg.stripe_world, cfg.stripe_rank, owned_rows);
+    if (!no_spec && !timed && cfg.stripe_world <= 1 && ev_call_done_ && read_stream_ && win.total <= nown && nxt.total != 0 && win.total + nxt.total <= nown) {
+        const size_t bk = (size_t)50 * cfg.width;
+        if (!d_bk_sum_) {
+            if (hipMalloc((void**)&d_bk_sum_, bk * 12) != hipSuccess || hipMalloc((void**)&d_bk_sumsq_, bk * 12) != hipSuccess || hipMalloc((void**)&d_bk_n_, bk * 4) != hipSuccess
+                || hipMalloc((void**)&d_counters_spec_, sizeof(DCounters) * kShards) != hipSuccess || hipHostMalloc((void**)&h_counters_spec_, sizeof(DCounters) * kShards, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError(); return 50u * cfg.width;            // no room to speculate: the frame asked for is queued all the same
+            }
+            allocs_.push_back(d_bk_sum_); allocs_.push_back(d_bk_sumsq_); allocs_.push_back(d_bk_n_); allocs_.push_back(d_counters_spec_);
+        }
+        bool ok = launch_film_rows_copy(stream_, d_owned_rows_, nxt.first, nxt.total, nown, cfg.width, d_film_sum_, d_film_sumsq_, d_film_n_, d_bk_sum_, d_bk_sumsq_, d_bk_n_, false) == hipSuccess
+                  && hipMemsetAsync(d_counters_spec_, 0, sizeof(DCounters) * kShards, stream_) == hipSuccess
+                  && launch_fused_window(nxt.first, nxt.total, cam, d_counters_spec_)
+                  && hipMemcpyAsync(h_counters_spec_, d_counters_spec_, sizeof(DCounters) * kShards, hipMemcpyDeviceToHost, stream_) == hipSuccess
+                  && hipEventRecord(ev_spec_done_, stream_) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); HIP_TRY(hipStreamSynchronize(stream_));        // what was queued of it ran; put the rows back and go on without
+                   (void)launch_film_rows_copy(stream_, d_owned_rows_, nxt.first, nxt.total, nown, cfg.width, d_film_sum_, d_film_sumsq_, d_film_n_, d_bk_sum_, d_bk_sumsq_, d_bk_n_, true); }
+        else { spec_.valid = true; spec_.row = current_row; spec_.first = nxt.first; spec_.total = nxt.total; spec_.next_row = nxt.next_row; spec_.cam_key = cam_key; spec_.seed = cfg.seed; spec_.flags = cfg.flags; ++spec_launched_; }
+    }
     return 50u * cfg.width;
+}
+
+// one launch of the fused kernel over `total` rows of the owned-row list from entry `first` (cyclic), 1 sample per pixel
+bool Renderer::launch_fused_window(uint32_t first, uint32_t total, const DCamera& cam, DCounters* dcounters)
+{
+    const uint32_t nown = (uint32_t)owned_rows.size();
+    Slice& sl = slices_[0];
+    const size_t nsamples = (size_t)total * cfg.width;
+    if (!ensure_pass_capacity(sl, nsamples)) return false;
+    DPass ps;
+    uint32_t fchunk = 32u;                                            // samples per wave (a 4x8 pixel tile): 64 / 32 / 16 measure 0.303 / 0.266 / 0.277 ms per launch
+    if (const char* e = getenv("MI355RT_FUSED_CHUNK")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fchunk = (uint32_t)v; }   // <= 64: the LDS lists hold one row per record of a sample; >= kMinChunk: the counts arrays
+    describe_pass(ps, sl, d_owned_rows_, first, nown, (uint32_t)nsamples, nsamples, fchunk, false, 0, 0);
+    if (ps.nchunks > sl.count_entries || (size_t)ps.nchunks * ps.region > sl.queue_records) { last_error = "internal: fused pass does not fit the pass buffers"; return false; }
+    hipError_t e = launch_fused_pass(stream_, num_cus_, mode_ == kModeConfirm, dscene_, cam, ps, max_level_nodes_, records_per_sample_, sl.d_queue[0], sl.d_queue[1],
+                                     sl.d_hits, sl.d_slot_L, sl.d_sample_slot, d_film_sum_, d_film_sumsq_, d_film_n_, dcounters);
+    if (e != hipSuccess) return fail(e, "fused pass launch");
+    return true;
+}
+
+// A speculative 50-row frame is out and the caller did something else: its rows go back to what they were (stream-ordered behind it).
+bool Renderer::settle_speculation()
+{
+    if (!spec_.valid) return true;
+    spec_.valid = false;
+    if (!bind()) return false;
+    HIP_TRY(launch_film_rows_copy(stream_, d_owned_rows_, spec_.first, spec_.total, (uint32_t)owned_rows.size(), cfg.width, d_film_sum_, d_film_sumsq_, d_film_n_, d_bk_sum_, d_bk_sumsq_, d_bk_n_, true));
+    return true;
 }
 
 bool Renderer::render(uint32_t spp, bool wait)
@@ -1147,15 +1214,26 @@ bool Renderer::get_tonemapped(uint32_t* out, size_t n)
     const size_t npix = (size_t)cfg.width * cfg.height;
     if (n < npix || !out) { last_error = "output buffer too small"; return false; }
     if (!h_ldr_) HIP_TRY(hipHostMalloc((void**)&h_ldr_, npix * 4, hipHostMallocDefault));
+    // A speculative frame may be changing rows right now (trace_frame_additive).  Rows it touches that have to be read (everything is dirty after a
+    // clear) would show samples the caller has not asked for yet: then the speculation is given up.  Otherwise the read-out runs beside it, on its own
+    // stream, behind the frame the caller did ask for.
+    if (spec_.valid) {
+        bool clash = false;
+        const uint32_t nown = (uint32_t)owned_rows.size();
+        for (uint32_t i = 0; i < spec_.total && !clash; ++i) clash = ldr_dirty_[owned_rows[(spec_.first + i) % nown]] != 0;
+        if (clash && !settle_speculation()) return false;
+    }
+    hipStream_t rs = stream_;
+    if (spec_.valid && call_done_valid_ && read_stream_) { HIP_TRY(hipStreamWaitEvent(read_stream_, ev_call_done_, 0)); rs = read_stream_; }
     for (uint32_t r = 0; r < cfg.height;) {
         if (!ldr_dirty_[r]) { ++r; continue; }
         uint32_t e = r;
         while (e < cfg.height && ldr_dirty_[e]) ldr_dirty_[e++] = 0;
-        HIP_TRY(launch_tonemap(stream_, nullptr, r, e - r, cfg.width, false, d_film_sum_, d_film_n_, d_ldr_));
-        HIP_TRY(hipMemcpyAsync(h_ldr_ + (size_t)r * cfg.width, d_ldr_ + (size_t)r * cfg.width, (size_t)(e - r) * cfg.width * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(launch_tonemap(rs, nullptr, r, e - r, cfg.width, false, d_film_sum_, d_film_n_, d_ldr_));
+        HIP_TRY(hipMemcpyAsync(h_ldr_ + (size_t)r * cfg.width, d_ldr_ + (size_t)r * cfg.width, (size_t)(e - r) * cfg.width * 4, hipMemcpyDeviceToHost, rs));
         r = e;
     }
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipStreamSynchronize(rs));
     std::memcpy(out, h_ldr_, npix * 4);
     return true;
 }
@@ -1167,6 +1245,7 @@ bool Renderer::get_tonemapped(uint32_t* out, size_t n)
 bool Renderer::tonemap_owned_rows_device(uint32_t* device_out, size_t n, hipStream_t caller_stream)
 {
     if (!bind()) return false;
+    if (!settle_speculation()) return false;
     if (n < owned_rows.size() * (size_t)cfg.width || !device_out) { last_error = "output buffer too small"; return false; }
     if (caller_stream) {
         HIP_TRY(hipEventRecord(slices_[0].done, stream_));
@@ -1186,6 +1265,7 @@ bool Renderer::synchronize()
 {
     if (!bind()) return false;
     for (Slice& o : slices_) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
+    if (read_stream_) HIP_TRY(hipStreamSynchronize(read_stream_));
     return true;
 }
 
@@ -1238,6 +1318,7 @@ bool Renderer::gather_prepare(bool root)
 bool Renderer::tonemap_to_gather_slot()
 {
     if (!bind()) return false;
+    if (!settle_speculation()) return false;
     HIP_TRY(launch_tonemap(stream_, d_owned_rows_, 0, (uint32_t)owned_rows.size(), cfg.width, true, d_film_sum_, d_film_n_, gather_slot(cfg.stripe_rank)));
     return true;
 }
@@ -1259,6 +1340,7 @@ bool Renderer::finish_gather(uint32_t* host_out, size_t n)
 bool Renderer::film_get(float* sum, float* sumsq, uint32_t* n)
 {
     if (!bind()) return false;
+    if (!settle_speculation()) return false;
     const size_t npix = (size_t)cfg.width * cfg.height;
     HIP_TRY(hipStreamSynchronize(stream_));
     if (sum) HIP_TRY(hipMemcpy(sum, d_film_sum_, npix * 12, hipMemcpyDeviceToHost));
@@ -1270,6 +1352,7 @@ bool Renderer::film_get(float* sum, float* sumsq, uint32_t* n)
 bool Renderer::film_clear()
 {
     if (!bind()) return false;
+    if (!settle_speculation()) return false;
     const size_t npix = (size_t)cfg.width * cfg.height;
     std::fill(ldr_dirty_.begin(), ldr_dirty_.end(), (uint8_t)1);     // unsampled rows read back white (NaN -> 255)
     if (cfg.stripe_world > 1) {
@@ -1386,6 +1469,7 @@ bool Renderer::debug_slab(const float* inv_rays6, const float* cubes6, size_t n,
 bool Renderer::film_stat(bool variances, float* rgb)
 {
     if (!bind()) return false;
+    if (!settle_speculation()) return false;
     const size_t npix = (size_t)cfg.width * cfg.height;
     float* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, npix * 12));
@@ -1402,6 +1486,8 @@ bool Renderer::debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, fl
 {
     if (!bind()) return false;
     if (nodes < nodes_per_sample || pixel >= cfg.width * cfg.height) { last_error = "bad debug_sample arguments"; return false; }
+    if (!settle_speculation()) return false;
+    call_done_valid_ = false;
     HIP_TRY(hipMemsetAsync(d_counters_, 0, sizeof(DCounters) * kShards, stream_));
     ev_used_ = 0; counts_pending_ = false;
     if (!run_pass(slices_[0], nullptr, 0, 1, 1, true, pixel, sampleno)) return false;

@@ -169,6 +169,19 @@ private:
     uint64_t pending_primary_ = 0;
     bool pending_timed_ = false;         // the pending call was a whole frame: its HIP-event time is read with the counters
     DCounters* d_counters_ = nullptr;
+    // Speculation of the drop-in loop (trace_frame_additive): the NEXT 50-row frame is launched right behind the one just asked for, so that the device
+    // traces it while the host reads out the current one (main.rs:197-207 alternates the two calls; one frame keeps the chip busy for 0.25 ms of latency,
+    // not of work).  The rows it changes are backed up first; a next call that is not the predicted one (camera moved, film cleared, anything else
+    // touched) puts them back.  Read-outs of the finished frame run on read_stream_, beside the speculative launch.
+    struct Speculation { bool valid = false; uint32_t row = 0, first = 0, total = 0, next_row = 0; std::vector<float> cam_key; uint64_t seed = 0; uint32_t flags = 0; } spec_;
+    DCounters* d_counters_spec_ = nullptr; DCounters* h_counters_spec_ = nullptr;
+    float* d_bk_sum_ = nullptr; float* d_bk_sumsq_ = nullptr; uint32_t* d_bk_n_ = nullptr;
+    hipStream_t read_stream_ = nullptr;
+    hipEvent_t ev_call_done_ = nullptr, ev_spec_done_ = nullptr;      // behind the kernel (and the counters' copy) of the frame last asked for / of the speculative one
+    bool call_done_valid_ = false;        // ev_call_done_ marks the last 50-row frame: read-outs wait for it, not for the stream
+    uint64_t spec_launched_ = 0, spec_adopted_ = 0;
+    bool settle_speculation();            // put the speculative frame's rows back (if one is out)
+    bool launch_fused_window(uint32_t first, uint32_t total, const DCamera& cam, DCounters* dcounters);
     DCounters* h_counters_ = nullptr;    // pinned host mirror (queue_counts_copy)
     float* d_debug_color_ = nullptr;
     static constexpr uint32_t kMaxSlices = 8;
