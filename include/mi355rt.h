@@ -246,6 +246,9 @@ int mi355rt_debug_numerics(mi355rt_handle* h, const float* a, const float* b, si
  * reference's own known-answer vectors (oct_tree_intersector.rs:475-512) run through the HIP path. */
 int mi355rt_debug_slab(mi355rt_handle* h, const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h);
+/* Speculation of the drop-in loop: out[0] = 50-row frames launched ahead of the call that asks for them, out[1] = how many of those the next
+ * mi355rt_trace_frame_additive call took over (the others were given back: the caller did something else first).  Test hook; device 0 of a group. */
+int mi355rt_debug_speculation(const mi355rt_handle* h, uint64_t out[2]);
 /* The depth cube map the library builds around a point light (csrc/lightmap.hpp; what lets the shade kernels leave out the shadow rays of
  * mod.rs:224-232 whose way to the light is provably free).  HOST code, no device needed: out_dist2[6 * res * res] receives, per direction texel
  * (face = 2 * major axis + (component negative), then i over the lower and j over the higher of the two other axes), a lower bound of the squared

@@ -131,6 +131,7 @@ ABI = [
     ("mi355rt_debug_numerics", C.c_int, [_H, _F, _F, C.c_size_t, _F, _F, _F]),
     ("mi355rt_debug_slab", C.c_int, [_H, _F, _F, C.c_size_t, C.POINTER(C.c_uint8), _F]),
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
+    ("mi355rt_debug_speculation", C.c_int, [_H, C.POINTER(C.c_uint64)]),
     ("mi355rt_debug_light_map", C.c_int, [_F, C.c_uint32, _F, C.c_double, C.c_uint32, _F, C.POINTER(C.c_double)]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
     ("mi355rt_octree_stats", C.c_int, [_H, _U]),
@@ -358,6 +359,12 @@ class RayTracer:
         out = (C.c_double * 3)()
         self._check(lib().mi355rt_debug_gather_rate(self._h, table_nodes, steps, out))
         return {"line_accesses_per_s": out[0], "ms": out[1], "node_fetches_per_s": out[2]}
+
+    def debug_speculation(self):
+        """(50-row frames launched ahead of their call, how many the next call took over)"""
+        out = (C.c_uint64 * 2)()
+        self._check(lib().mi355rt_debug_speculation(self._h, out))
+        return int(out[0]), int(out[1])
 
     def debug_check_guards(self):
         """MI355RT_DEBUG_GUARD: overwritten guard bytes behind the pass buffers (0 = clean)"""

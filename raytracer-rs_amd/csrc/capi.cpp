@@ -278,6 +278,12 @@ int mi355rt_debug_slab(mi355rt_handle* h, const float* inv_rays6, const float* c
     return h->r->debug_slab(inv_rays6, cubes6, n, hit, tmin) ? MI355RT_OK : MI355RT_E_HIP;
 }
 uint32_t mi355rt_tree_nodes(const mi355rt_handle* h) { return h ? h->r->nodes_per_sample : 0u; }
+int mi355rt_debug_speculation(const mi355rt_handle* h, uint64_t out[2])
+{
+    if (!h || !out) return MI355RT_E_INVALID;
+    h->r->speculation_stats(out);
+    return MI355RT_OK;
+}
 int mi355rt_debug_light_map(const float* tri_verts, uint32_t ntri, const float light[3], double pad, uint32_t res, float* out_dist2, double* nearest)
 {
     if ((ntri && !tri_verts) || !light || !out_dist2 || res == 0 || res > 4096 || !(pad >= 0.0)) return MI355RT_E_INVALID;

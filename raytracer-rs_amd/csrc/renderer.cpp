@@ -1075,7 +1075,7 @@ uint32_t Renderer::trace_frame_additive()
     // The next frame, speculatively (see renderer.hpp): only in the plain case — the whole image on one device (striped handles and device-group members
     // read their pixels out through paths that would give every speculation up), one launch per frame, two consecutive windows that share no row,
     // no instrumentation.
-    static const bool no_spec = getenv("MI355RT_NO_SPECULATE") != nullptr;
+    const bool no_spec = getenv("MI355RT_NO_SPECULATE") != nullptr;
     const FrameWindow nxt = frame_window(current_row, cfg.height, cfg.stripe_rows, cfg.stripe_world, cfg.stripe_rank, owned_rows);
     if (!no_spec && !timed && cfg.stripe_world <= 1 && ev_call_done_ && read_stream_ && win.total <= nown && nxt.total != 0 && win.total + nxt.total <= nown) {
         const size_t bk = (size_t)50 * cfg.width;

@@ -50,6 +50,7 @@ public:
     bool debug_gather_rate(uint32_t table_nodes, uint32_t steps, double out[3]);
     bool debug_slab(const float* inv_rays6, const float* cubes6, size_t n, uint8_t* hit, float* tmin);
     bool film_stat(bool variances, float* rgb);
+    void speculation_stats(uint64_t out[2]) const { out[0] = spec_launched_; out[1] = spec_adopted_; }
     bool debug_numerics(const float* a, const float* b, size_t n, float* q, float* r, float* p);
     bool debug_sample(uint32_t pixel, uint32_t sampleno, float* color3, float* node_L, size_t nodes);
 

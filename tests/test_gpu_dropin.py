@@ -177,6 +177,64 @@ def test_dropin_loop_thai2_1024x768_matches_oracle(pkg, scenes, oracle):
     assert (g == 0xFFFFFFFF).mean() > 0.9
 
 
+@pytest.mark.parametrize("speculate", [True, False])
+def test_speculated_frames_are_taken_over_or_given_back(pkg, scenes, oracle, monkeypatch, speculate):
+    """The library launches the NEXT 50-row frame behind the one asked for (the reference's loop alternates trace_frame_additive and
+    get_tonemapped_pixels, main.rs:197-207).  Whatever the caller does instead of the predicted call must see the film as if nothing had been
+    launched ahead: a film read-out, a camera move WITHOUT a clear, a clear, a new seed, a whole-frame render, the row-index flag, a call right after
+    creation — each followed by more frames; film, pixels, current row and the per-call counters equal the oracle's after every step.  The same
+    sequence with MI355RT_NO_SPECULATE is the control."""
+    if not speculate:
+        monkeypatch.setenv("MI355RT_NO_SPECULATE", "1")
+    else:
+        monkeypatch.delenv("MI355RT_NO_SPECULATE", raising=False)
+    w, h = 320, 240
+    name = "ico2"
+    rt = make(pkg, scenes, name, w, h, seed=3)
+    orc = oracle.Oracle(scenes(name), w, h, seed=3)
+    buf = np.empty(w * h, np.uint32)
+
+    def frame(check_counts=True):
+        before = orc.counters()
+        assert rt.trace_frame_additive() == orc.trace_frame_additive() == 50 * w
+        after = orc.counters()
+        if check_counts:
+            c = rt.last_counts()
+            assert (c.primary, c.bounce, c.shadow, c.primary_hits) == tuple(after[k] - before[k] for k in ("primary", "bounce", "shadow", "primary_hits"))
+
+    def same_film():
+        gs, gq, gn = rt.film.pixel_datas(); os_, oq, on = orc.film()
+        assert np.array_equal(gn, on) and np.array_equal(bits(gs), bits(os_)) and np.array_equal(bits(gq), bits(oq))
+        assert rt.current_row == orc.current_row
+
+    def same_pixels():
+        assert np.array_equal(rt.get_tonemapped_pixels(buf), orc.get_tonemapped_pixels())
+
+    frame(); same_pixels(); frame(False); same_pixels(); frame()
+    same_film()                                                  # a film read-out while the next frame is out
+    frame(); same_pixels()
+    rt.camera.move_rel(0.2, -0.1, 0.1); orc.camera_move_rel(0.2, -0.1, 0.1)          # the camera moves, the film stays (not what the reference's loop does, but allowed)
+    frame(); same_pixels(); same_film()
+    frame(False); frame(False); same_pixels()                    # frames without read-outs in between
+    rt.film.clear(); orc.film_clear()
+    same_pixels()                                                # everything white
+    frame(); same_pixels(); same_film()
+    rt.set_seed(77); orc.set_seed(77)
+    frame(); frame(); same_film()
+    rt.render(2); orc.render(2, nthreads=4)                      # a whole-frame render in between
+    same_film(); frame(); same_pixels(); same_film()
+    rt.set_flags(pkg.FLAG_FIX_ROW_INDEX); orc.set_flags(oracle.FLAG_FIX_ROW_INDEX)
+    frame(); same_pixels(); frame(); same_film()
+    for _ in range(6):                                           # through the wrap of the row cursor
+        frame(False)
+    same_pixels(); same_film()
+    launched, taken = rt.debug_speculation()
+    if speculate:
+        assert launched > 10 and 5 < taken < launched           # both outcomes happened
+    else:
+        assert (launched, taken) == (0, 0)
+
+
 def test_fused_frame_equals_wavefront_rounds(pkg, scenes):
     """The single-launch frame kernel and the multi-launch wavefront rounds are the same arithmetic: identical
     films and counters — also with stripes (rank 1 of 3 owns every third block of 4 rows, so a 50-row window holds
