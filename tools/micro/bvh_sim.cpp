@@ -169,8 +169,22 @@ int main(int argc, char** argv)
     Matrix m; std::memcpy(m.e, s.cameras[0].orientation, 64);
     Camera cam = Camera::from_orientation_matrix(W, H, m, s.cameras[0].fov_deg);
     std::mt19937 rng(1); std::uniform_real_distribution<float> U(0.0f, 1.0f), S(-1.0f, 1.0f);
-    Stats prim, refl1, refl2, shadow, p_refl1, p_refl2, p_shadow;
+    Stats prim, refl1, refl2, shadow, p_refl1, p_refl2, p_shadow, c_refl1, c_refl2;
     build_paths(bvh);
+    // upper bound of what an "escape" table could buy (profiles/r03_notes.md): a reflection ray that misses everything is traced again with its search cut
+    // at the point where it leaves the 3 x 3 x 3 block of grid cells around its origin (a table that KNEW it escapes would allow exactly that)
+    const int GRID = getenv("SIM_GRID") ? atoi(getenv("SIM_GRID")) : 32;
+    auto block_exit = [&](const float o[3], const float d[3]) {
+        float t_exit = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = bvh.scene_min[a], hi = bvh.scene_max[a], cs = (hi - lo) / GRID;
+            int c = (int)std::floor((o[a] - lo) / cs); c = std::max(0, std::min(GRID - 1, c));
+            const float b0 = lo + (c - 1) * cs, b1 = lo + (c + 2) * cs;
+            if (d[a] > 0) t_exit = std::min(t_exit, (b1 - o[a]) / d[a]);
+            else if (d[a] < 0) t_exit = std::min(t_exit, (b0 - o[a]) / d[a]);
+        }
+        return t_exit;
+    };
     auto reflect = [&](const float o[3], const float d[3], const HitRec& h, float ro[3], float rd[3]) {
         const BvhTri& t = bvh.tris[h.bvh_tri];
         float n[3] = { t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1], t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2], t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0] };
@@ -202,16 +216,19 @@ int main(int argc, char** argv)
         for (int c = 0; c < 2; ++c) {
             float ro[3], rd[3]; reflect(o, d, h, ro, rd);
             HitRec h1 = trace(bvh, ro, rd, INFINITY, refl1);
+            trace(bvh, ro, rd, h1.prim == 0xFFFFFFFFu ? block_exit(ro, rd) : INFINITY, c_refl1);
             { HitRec b = trace(bvh, ro, rd, INFINITY, p_refl1, (int)h.bvh_tri); if (b.prim != h1.prim || b.t != h1.t) std::printf("MISMATCH r1\n"); }
             if (h1.prim == 0xFFFFFFFFu) continue;
             shadow_ray(ro, rd, h1);
             float ro2[3], rd2[3]; reflect(ro, rd, h1, ro2, rd2);
             HitRec h2 = trace(bvh, ro2, rd2, INFINITY, refl2);
+            trace(bvh, ro2, rd2, h2.prim == 0xFFFFFFFFu ? block_exit(ro2, rd2) : INFINITY, c_refl2);
             { HitRec b = trace(bvh, ro2, rd2, INFINITY, p_refl2, (int)h1.bvh_tri); if (b.prim != h2.prim || b.t != h2.t) std::printf("MISMATCH r2\n"); }
             if (h2.prim != 0xFFFFFFFFu) shadow_ray(ro2, rd2, h2);
         }
     }
     prim.print("primary"); refl1.print("reflect 1"); refl2.print("reflect 2"); shadow.print("shadow");
+    c_refl1.print("C reflect1"); c_refl2.print("C reflect2");
     p_refl1.print("P reflect1"); p_refl2.print("P reflect2"); p_shadow.print("P shadow");
     std::printf("path rays %.0f: slot loads per ray %.2f, of which hit (pushed) %.2f\n", g_path_rays, g_slot_loads / g_path_rays, g_slot_hits / g_path_rays);
     auto loads = [](const Stats& a) { return (2.0 * a.visits + 3.0 * a.tris) / a.rays; };
