@@ -1270,8 +1270,11 @@ __device__ __forceinline__ void resolve_chunk_1spp(const DPass& ps, uint32_t wid
     }
 }
 
+#ifndef MI355RT_FUSED_BLOCKS
+#define MI355RT_FUSED_BLOCKS 1                 // blocks per CU the fused 50-row kernel is compiled for (A/B knob: 4 = 128 VGPRs)
+#endif
 template <bool CONFIRM>
-__global__ __launch_bounds__(kBlock) void fused_pass_kernel(DScene sc, DCamera cam, DPass ps, float4* q0, float4* q1,
+__global__ __launch_bounds__(kBlock, MI355RT_FUSED_BLOCKS) void fused_pass_kernel(DScene sc, DCamera cam, DPass ps, float4* q0, float4* q1,
                                                             float4* hits, float* slot_L, uint32_t* sample_slot,
                                                             float* film_sum, float* film_sumsq, uint32_t* film_n, DCounters* counters)
 {
