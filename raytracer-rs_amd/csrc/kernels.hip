@@ -509,6 +509,17 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
 #ifdef MI355RT_EXP_NOSHADOW      // timing experiment (wrong results): shadow rays are not traced at all — what do they cost?
                 if (shadow) rs.node = kNodeFin;
 #endif
+#ifdef MI355RT_EXP_PATHLOADS     // timing experiment (same results): what would reading a 13-slot path record per secondary ray ADD?  Rays that start within 0.01 of each other read the same record
+                if (!PRIMARY) {
+                    const uint32_t hx = (uint32_t)(int)floorf(o.x * 100.0f) * 73856093u ^ (uint32_t)(int)floorf(o.y * 100.0f) * 19349663u ^ (uint32_t)(int)floorf(o.z * 100.0f) * 83492791u;
+                    const uint4* __restrict__ t4 = (const uint4*)sc.tris;
+                    const uint32_t b0 = hx % (sc.ntri * 3u - 16u);
+                    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (uint32_t k = 0; k < 13u; ++k) { const uint4 q = t4[b0 + k]; acc.x ^= q.x; acc.y ^= q.y; acc.z ^= q.z; acc.w ^= q.w; }
+                    asm volatile("" : : "v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));
+                }
+#endif
             }
             w_next += min((uint32_t)__popcll(idle), avail);
             idle = __ballot(rs.node == kNodeIdle);
