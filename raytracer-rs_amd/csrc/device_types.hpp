@@ -112,6 +112,12 @@ struct DPass {
     // paid a pull, a count load and a loop set-up for each of them (1.35 ms per frame with every chunk empty).  The primary shade launch appends
     // every chunk it leaves rays in to the list of cursor (chunk % ncursors): live[k * live_cap ...], length in live_count[k * 16384 + kLiveCountOffset];
     // the launches of the later rounds hand out list entries instead of chunk numbers (pull_chunk).  null: every launch walks all chunks.
+    // Cached culling verdicts (round 3): whether a chunk is culled depends on its pixels, not on its sample numbers, and a pass whose sample groups are
+    // whole numbers of chunks repeats the same pixel blocks in every group.  block_culled[chunk % cull_blocks] != 0: the chunk's primary samples all miss
+    // (chunk_is_culled, evaluated once per camera and layout by cull_blocks_kernel instead of by every launch for every chunk); the primary shade launch
+    // then writes nothing for such a chunk and the resolve launch reads nothing.  null: every launch evaluates chunk_is_culled itself.
+    const uint32_t* block_culled;
+    uint32_t cull_blocks;
     uint32_t* live;
     uint32_t* live_count;
     uint32_t live_cap;

@@ -30,6 +30,7 @@
 // shading, camera, film, tonemap) is IEEE f32 in the reference's operation order.  Only the BVH box
 // tests are free-form: boxes are padded (bvh.cpp) and the test is conservative.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdlib.h>
 #include <map>
@@ -42,6 +43,7 @@
 
 namespace mi355rt {
 
+typedef const uint32_t __attribute__((address_space(4))) * const_u1_ptr;    // constant address space: a wave-uniform address loads through the scalar cache
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr uint32_t kMiss = 0xFFFFFFFFu;
@@ -99,7 +101,6 @@ __device__ __forceinline__ uint32_t global_wave_id() { return blockIdx.x * kWave
 // dynamic rest, several chunks per pull, draining more than 8 cursors, heaviest-chunks-first order.
 constexpr uint32_t kCursorStride = kCtrlWordsPerRound / kMaxCursors;   // u32 words between cursors (64 KiB): atomics to nearby lines serialise on one memory channel
 static_assert(kCursorStride == 16384 && kShadeCursorOffset == 2 * kConfirmCursorOffset && kLiveCountOffset == 3 * kConfirmCursorOffset, "cursor layout (device_types.hpp) and the reset loop of resolve_kernel");
-typedef const uint32_t __attribute__((address_space(4))) * const_u1_ptr;    // constant address space: a wave-uniform address loads through the scalar cache
 struct PullState { bool first = true; uint32_t shard = 0u, tries = 0u, left = 0u, part = 0xFFFFFFFFu; };
 // the live-chunk lists of a pass (DPass::live): cursor k hands out the entries of list k instead of the chunk numbers k, k + ncursors, ...
 struct LiveLists { const uint32_t* list = nullptr; const uint32_t* count = nullptr; uint32_t cap = 0u; };
@@ -350,6 +351,13 @@ __device__ __forceinline__ bool chunk_is_culled(const DCamera& cam, const DPass&
     return __ballot(word != 0u) == 0ull;
 }
 
+// the verdict, cached per pixel block of the pass when the host had it computed (DPass::block_culled), else computed here
+__device__ __forceinline__ bool chunk_culled(const DCamera& cam, const DPass& ps, uint32_t chunk, uint32_t n)
+{
+    if (ps.block_culled != nullptr) return ((const_u1_ptr)(uintptr_t)ps.block_culled)[chunk % ps.cull_blocks] != 0u;
+    return chunk_is_culled(cam, ps, chunk, n);
+}
+
 // record index of ray i of a chunk: radiance rays from the front, shadow rays from the back
 __device__ __forceinline__ size_t record_index(const DPass& ps, uint32_t chunk, uint32_t i, uint32_t n_rad)
 {
@@ -464,7 +472,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
                 w_chunk = bcast_first(c); w_next = 0u;
                 if (PRIMARY) {
                     w_nrad = min(ps.chunk, ps.nsamples - w_chunk * ps.chunk);
-                    if (chunk_is_culled(cam, ps, w_chunk, w_nrad)) w_nrad = 0u;    // the shade kernel makes the same decision
+                    if (chunk_culled(cam, ps, w_chunk, w_nrad)) w_nrad = 0u;    // the shade kernel makes the same decision
                     w_nrad = bcast_first(w_nrad);
                     w_ntot = w_nrad;
                 }
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(kBlock) void raster_kernel(DScene sc, DCamera cam, 
     PullState pull; uint32_t chunk = 0u;
     while (pull_chunk(cursor, ps.nchunks, ps.pull_mode, ps.ncursors, ps.pull_group, pull, chunk)) {
         const uint32_t n = min(ps.chunk, ps.nsamples - chunk * ps.chunk);
-        if (chunk_is_culled(cam, ps, chunk, n)) continue;               // the shade kernel makes the same decision
+        if (chunk_culled(cam, ps, chunk, n)) continue;               // the shade kernel makes the same decision
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             const uint32_t i = i0 + (uint32_t)lane;
             const bool valid = i < n;
@@ -755,7 +763,7 @@ __device__ __forceinline__ void confirm_chunk(const DScene& sc, const DCamera& c
     const int lane = lane_id();
     if (PRIMARY) {
         n_rad = min(ps.chunk, ps.nsamples - chunk * ps.chunk); n_sh = 0u;
-        if (chunk_is_culled(cam, ps, chunk, n_rad)) return;                 // nothing was traced, nothing was hit
+        if (chunk_culled(cam, ps, chunk, n_rad)) return;                 // nothing was traced, nothing was hit
     }
     const uint32_t n_tot = n_rad + n_sh;
     uint32_t cnt = 0u;
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(kBlock, MI355RT_CONFIRM_BLOCKS) void confirm_kernel
         uint32_t n_rad = 0u, n_sh = 0u;
         if (PRIMARY) {
             n_rad = min(ps.chunk, ps.nsamples - chunk * ps.chunk);
-            if (chunk_is_culled(cam, ps, chunk, n_rad)) continue;
+            if (chunk_culled(cam, ps, chunk, n_rad)) continue;
         } else { const uint2 n = in_counts[chunk]; n_rad = n.x; n_sh = n.y; }
         const uint32_t n_tot = n_rad + n_sh;
         for (uint32_t it = shadow_only ? n_rad : 0u; it < n_tot; it += 64u) {     // shadow_only: the shade kernel of the round confirms the radiance hits itself
@@ -905,9 +913,9 @@ __device__ __forceinline__ void shade_chunk(const DScene& sc, const DCamera& cam
     {
         uint32_t n_rad = PRIMARY ? min(ps.chunk, ps.nsamples - chunk * ps.chunk) : in_nrad;
         const size_t base = (size_t)chunk * ps.region;
-        if (PRIMARY && chunk_is_culled(cam, ps, chunk, n_rad)) {
-            // no hit records were written for this chunk: every sample is a miss
-            for (uint32_t i = (uint32_t)lane; i < n_rad; i += 64u) sample_slot[chunk * ps.chunk + i] = kMiss;
+        if (PRIMARY && chunk_culled(cam, ps, chunk, n_rad)) {
+            // no hit records were written for this chunk: every sample is a miss (with cached verdicts the resolve launch knows that too and reads no slot)
+            if (ps.block_culled == nullptr) for (uint32_t i = (uint32_t)lane; i < n_rad; i += 64u) sample_slot[chunk * ps.chunk + i] = kMiss;
             acc_hits += (unsigned long long)n_rad << 32;         // high half: primary samples skipped by the frustum culling
             n_rad = 0u;
         }
@@ -1209,8 +1217,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(DPass ps, uint32_t width, 
         n = film_n[pixel];
     }
     const int group_lane0 = lane_id() & ~(int)(kResolveLanes - 1u);
+    // every sample of a pixel in a culled block is a miss: no slot to look up (the primary shade launch wrote none)
+    const bool dead = ps.block_culled != nullptr && ps.block_culled[(uint32_t)(sample_index(ps, 0u, p) / ps.chunk) % ps.cull_blocks] != 0u;
     for (uint32_t s0 = 0; s0 < spp; s0 += kResolveLanes) {
-        const uint32_t sl = s0 + j < spp ? sample_slot[sample_index(ps, s0 + j, p)] : 0xFFFFFFFFu;
+        const uint32_t sl = (s0 + j < spp && !dead) ? sample_slot[sample_index(ps, s0 + j, p)] : 0xFFFFFFFFu;
         const float* L = slot_L + 3ull * (size_t)sl;       // the slot's entry of plane 0; plane q is 3 * q * nslots floats further
         f3 c = mk3(0.0f, 0.0f, 0.0f);                                   // primary miss: RGB::black(), mod.rs:100
         if (sl != 0xFFFFFFFFu) switch (ps.recursions) {
@@ -1519,6 +1529,24 @@ hipError_t launch_trace(hipStream_t stream, int num_cus, int blocks_per_cu_cap, 
     if (confirm) return count ? launch_trace_variant<false, true, true>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, true>(MI355RT_TRACE_ARGS);
     return count ? launch_trace_variant<false, true, false>(MI355RT_TRACE_ARGS) : launch_trace_variant<false, false, false>(MI355RT_TRACE_ARGS);
 #undef MI355RT_TRACE_ARGS
+}
+
+// one wave per pixel block of the pass: the culling verdict of its chunk in the first sample group (DPass::block_culled)
+__global__ __launch_bounds__(kBlock) void cull_blocks_kernel(DCamera cam, DPass ps, uint32_t nblocks, uint32_t* out)
+{
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    for (uint32_t b = global_wave_id(); b < nblocks; b += nwaves) {
+        const bool culled = chunk_is_culled(cam, ps, b, ps.chunk);
+        if (lane_id() == 0) out[b] = culled ? 1u : 0u;
+    }
+}
+hipError_t launch_cull_blocks(hipStream_t stream, const DCamera& cam, const DPass& ps, uint32_t nblocks, uint32_t* out)
+{
+    if (nblocks == 0) return hipSuccess;
+    DPass plain = ps; plain.block_culled = nullptr; plain.cull_blocks = 0;
+    const unsigned blocks = std::min<unsigned>((nblocks + kWavesPerBlock - 1) / kWavesPerBlock, 4096u);
+    hipLaunchKernelGGL(cull_blocks_kernel, dim3(blocks), dim3(kBlock), 0, stream, cam, plain, nblocks, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_raster(hipStream_t stream, int num_cus, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,

@@ -12,6 +12,8 @@ hipError_t launch_trace(hipStream_t stream, int num_cus, int blocks_per_cu_cap, 
 // the primary rays' closest hits through the screen-space triangle bins (cam.tile_ofs != null); same outputs as the primary trace launch
 hipError_t launch_raster(hipStream_t stream, int num_cus, bool count, bool confirm, const DScene& sc, const DCamera& cam, const DPass& ps,
                          void* hits, uint32_t* cursor, const uint32_t* film_n, DCounters* counters);
+// culling verdicts of the pass's pixel blocks (DPass::block_culled): out[b] = chunk b (first sample group) is culled
+hipError_t launch_cull_blocks(hipStream_t stream, const DCamera& cam, const DPass& ps, uint32_t nblocks, uint32_t* out);
 hipError_t launch_trace_octree(hipStream_t stream, int num_cus, bool primary, const DScene& sc, const DCamera& cam, const DPass& ps,
                                const void* in_q, const void* in_counts, void* hits, float* slot_L, const uint32_t* film_n);
 hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk, const DScene& sc, const DCamera& cam, const DPass& ps, uint32_t level,

@@ -655,6 +655,7 @@ void Renderer::free_pass_buffers()
         if (sl.d_slot_L) { (void)hipFree(sl.d_slot_L); sl.d_slot_L = nullptr; }
         if (sl.d_sample_slot) { (void)hipFree(sl.d_sample_slot); sl.d_sample_slot = nullptr; }
         if (sl.d_live) { (void)hipFree(sl.d_live); sl.d_live = nullptr; }
+        if (sl.d_block_culled) { (void)hipFree(sl.d_block_culled); sl.d_block_culled = nullptr; sl.block_culled_cap = 0; sl.cull_key.clear(); }
         if (sl.d_slot_ps) { (void)hipFree(sl.d_slot_ps); sl.d_slot_ps = nullptr; }
         if (sl.d_hits) { (void)hipFree(sl.d_hits); sl.d_hits = nullptr; }
         if (sl.d_hit_prim) { (void)hipFree(sl.d_hit_prim); sl.d_hit_prim = nullptr; }
@@ -714,7 +715,7 @@ bool Renderer::assign_slice_rows(uint32_t nslices)
 {
     if (rows_assigned_for_ == nslices) return true;
     for (Slice& o : slices_) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
-    for (Slice& o : slices_) o.rows.clear();
+    for (Slice& o : slices_) { o.rows.clear(); o.cull_key.clear(); }       // other rows: other pixel blocks, other verdicts
     for (size_t i = 0; i < owned_rows.size(); ++i) slices_[(i / cfg.stripe_rows) % nslices].rows.push_back(owned_rows[i]);
     for (uint32_t s = 0; s < nslices; ++s)
         if (!slices_[s].rows.empty()) HIP_TRY(hipMemcpy(slices_[s].d_rows, slices_[s].rows.data(), slices_[s].rows.size() * 4, hipMemcpyHostToDevice));
@@ -787,6 +788,30 @@ bool Renderer::pass_begin(PassRun& run, Slice& sl, const uint32_t* d_rows, uint3
     // the tile bins of the primary rays need a pass that walks the slice's whole row list (render(); not the odd row windows of the other callers)
     const bool whole = !explicit_sample && d_rows == sl.d_rows && row0 == 0 && nrows == sl.rows.size() && row_wrap == 0xFFFFFFFFu;
     run.cam = device_camera(whole ? &run.ps : nullptr, whole ? &sl.rows : nullptr);
+    // culling verdicts per pixel block, computed once per camera and layout (DPass::block_culled) instead of per launch and chunk
+    run.ps.block_culled = nullptr; run.ps.cull_blocks = 0;
+    // (needs chunks that hold whole pixels — the sample group divides the chunk — and sample groups that are whole numbers of chunks: then every sample of a pixel
+    // lies in chunks of ONE block)
+    if (whole && run.cam.cull_valid != 0 && mode_ != kModeOctreeWalk && run.ps.chunk % run.ps.sample_group == 0 && ((size_t)run.ps.npix * run.ps.sample_group) % run.ps.chunk == 0 && !getenv("MI355RT_NO_CULL_CACHE")) {
+        const size_t nblocks = (size_t)run.ps.npix * run.ps.sample_group / run.ps.chunk;
+        std::vector<float> key(run.cam.rot, run.cam.rot + 16);
+        key.insert(key.end(), run.cam.origin, run.cam.origin + 3); key.push_back(run.cam.max_x); key.push_back(run.cam.max_y);
+        key.push_back((float)nrows); key.push_back((float)run.ps.chunk); key.push_back((float)run.ps.sample_group); key.push_back((float)run.ps.row_group);
+        key.push_back((float)(run.ps.flags & 1u)); key.push_back(run.cam.cull_mask ? 1.0f : 0.0f); key.push_back((float)nblocks);
+        if (nblocks > sl.block_culled_cap) {
+            HIP_TRY(hipStreamSynchronize(sl.stream));
+            if (sl.d_block_culled) { (void)hipFree(sl.d_block_culled); sl.d_block_culled = nullptr; sl.block_culled_cap = 0; }
+            if (hipMalloc((void**)&sl.d_block_culled, nblocks * 4) == hipSuccess) sl.block_culled_cap = nblocks; else { (void)hipGetLastError(); sl.d_block_culled = nullptr; }
+            sl.cull_key.clear();
+        }
+        if (sl.d_block_culled) {
+            if (key != sl.cull_key) {          // stream-ordered behind the launches that read the old verdicts
+                HIP_TRY(launch_cull_blocks(sl.stream, run.cam, run.ps, (uint32_t)nblocks, sl.d_block_culled));
+                sl.cull_key = key;
+            }
+            run.ps.block_culled = sl.d_block_culled; run.ps.cull_blocks = (uint32_t)nblocks;
+        }
+    }
     run.rounds = cfg.recursions + 2;
     // the work cursors: zeroed at creation and again by the resolve kernel of every pass that ran to its end (pass_end)
     if (!sl.ctrl_clean) HIP_TRY(hipMemsetAsync(sl.d_ctrl, 0, kMaxRounds * kCtrlWordsPerRound * 4, sl.stream));

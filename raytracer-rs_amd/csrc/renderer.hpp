@@ -112,6 +112,9 @@ private:
         void* d_slot_ps = nullptr;               // light-term slot -> (pixel, sample number) of its sample (uint2)
         uint32_t* d_sample_slot = nullptr;       // primary sample -> slot of its light terms (0xFFFFFFFF: the primary ray missed)
         uint32_t* d_live = nullptr;              // live-chunk lists of the pass, one per work cursor (DPass::live)
+        uint32_t* d_block_culled = nullptr;      // cached culling verdicts of the pass's pixel blocks (DPass::block_culled) for the camera / layout of cull_key
+        size_t block_culled_cap = 0;
+        std::vector<float> cull_key;
         size_t capacity = 0;                     // samples
         size_t queue_records = 0;
         size_t count_entries = 0;                // entries of each d_chunk_counts array

@@ -563,8 +563,8 @@ def test_chunk_culling_stages_never_change_a_frame(pkg, scenes, monkeypatch, nam
     and in a 50-row frame of the drop-in entry."""
     w, h, spp = 960, 540, 4
     films, culled = {}, {}
-    for mode, env in (("mask", {}), ("rects", {"MI355RT_NO_CULL_MASK": "1"}), ("none", {"MI355RT_NO_CULL": "1"})):
-        for k in ("MI355RT_NO_CULL_MASK", "MI355RT_NO_CULL"):
+    for mode, env in (("mask", {}), ("rects", {"MI355RT_NO_CULL_MASK": "1"}), ("none", {"MI355RT_NO_CULL": "1"}), ("uncached", {"MI355RT_NO_CULL_CACHE": "1"})):
+        for k in ("MI355RT_NO_CULL_MASK", "MI355RT_NO_CULL", "MI355RT_NO_CULL_CACHE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -583,7 +583,8 @@ def test_chunk_culling_stages_never_change_a_frame(pkg, scenes, monkeypatch, nam
         culled[mode] = (c0.primary_culled, c1.primary_culled, c2.primary_culled)
         assert (c0.primary, c1.primary) == (w * h * spp, w * h * spp)
         del rt
-    for mode in ("rects", "none"):
+    assert culled["uncached"] == culled["mask"]               # the verdicts cached per pixel block are the verdicts every launch used to compute
+    for mode in ("rects", "none", "uncached"):
         for a, b in zip(films["mask"], films[mode]):
             for x, y in zip(a, b):
                 assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), mode
