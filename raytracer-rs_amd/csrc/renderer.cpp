@@ -1183,7 +1183,12 @@ bool Renderer::render(uint32_t spp, bool wait)
                 const uint32_t rows_per_pass = (uint32_t)std::min<size_t>(snrows, std::max<size_t>(1, starget / cfg.width));
                 uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, starget / ((size_t)rows_per_pass * cfg.width)));
                 if (cfg.samples_per_pass) k = std::min(spp, cfg.samples_per_pass);
-                else { const uint32_t np = (spp + k - 1) / k; k = (spp + np - 1) / np; }     // equal passes: 48+16 -> 32+32
+                else {
+                    const uint32_t np = (spp + k - 1) / k; k = (spp + np - 1) / np;      // equal passes: 48+16 -> 32+32
+                    // ... of a multiple of 8 samples per pixel when there is room for it: 8 samples of a pixel sit together in the pass order (describe_pass), and the
+                    // tile bins of the primary rays and the cached culling verdicts need that group to divide the 64 samples of a wave (C5: 256 spp in passes of 18 had neither)
+                    if (k > 8u && k % 8u) { const uint32_t k8 = k / 8u * 8u; if ((size_t)rows_per_pass * cfg.width * (k8 + 8u) <= starget) k = k8 + 8u; else k = k8; }
+                }
                 ok = ensure_pass_capacity(sl, (size_t)rows_per_pass * cfg.width * std::min(k, spp));
                 for (uint32_t done = 0; ok && done < spp; done += k)
                     for (uint32_t r0 = 0; r0 < snrows; r0 += rows_per_pass)
