@@ -743,6 +743,9 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     // tile groups of 8 rows, or of the stripe height when rows are dealt (to ranks and to slices) in blocks of fewer rows: a group
     // that spans two blocks lying far apart in the image makes loose culling rectangles and incoherent tiles
     ps.row_group_shift = 3; while (ps.row_group_shift > 0 && (1u << ps.row_group_shift) > cfg.stripe_rows) --ps.row_group_shift;
+    // ... and of a height that divides the pass's rows when there is one (1050 rows: groups of 2, not 4 with a ragged last group): whole groups everywhere is what
+    // the tile bins of the primary rays need, and costs nothing
+    if (!explicit_sample && cfg.width) { const uint32_t prow = npix / cfg.width; while (ps.row_group_shift > 0 && prow % (1u << ps.row_group_shift)) --ps.row_group_shift; }
     ps.row_group = 1u << ps.row_group_shift;
     ps.seed = (uint32_t)cfg.seed; ps.flags = cfg.flags; ps.recursions = cfg.recursions; ps.spread = cfg.spread;
     ps.nodes_per_sample = nodes_per_sample;
