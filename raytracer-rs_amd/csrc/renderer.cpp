@@ -739,6 +739,8 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     if (const char* e = getenv("MI355RT_SAMPLE_GROUP")) { int v = atoi(e); if (v >= 1) group = (uint32_t)v; }
     group = std::max(1u, std::min(group, ps.spp));
     while (ps.spp % group) --group;
+    // a power of two by preference (12 spp: 4, not 6): the tile bins and the cached culling verdicts need the group to divide a wave's 64 samples
+    if (64u % group) { uint32_t p2 = 8u; while (p2 > 1u && (p2 > group || ps.spp % p2)) p2 >>= 1; group = p2; }
     ps.sample_group = group;
     // tile groups of 8 rows, or of the stripe height when rows are dealt (to ranks and to slices) in blocks of fewer rows: a group
     // that spans two blocks lying far apart in the image makes loose culling rectangles and incoherent tiles
