@@ -202,7 +202,9 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
         uint32_t res = 512;
         if (const char* e = getenv("MI355RT_LIGHT_MAP_RES")) { int v = atoi(e); if (v >= 16 && v <= 2048) res = (uint32_t)v; }
         while (res > 16 && (size_t)6 * res * res * 4 * scene.lights.size() > ((size_t)64 << 20)) res /= 2;
-        for (const LightData& l : scene.lights) while (res > 16 && light_map_work(scene.tri_verts.data(), ntri, l.pos, res) > (4ull << 20)) res /= 2;
+        uint64_t work_cap = 4ull << 20;
+        if (const char* e = getenv("MI355RT_LIGHT_MAP_WORK")) { long long v = atoll(e); if (v >= 1024) work_cap = (uint64_t)v; }
+        for (const LightData& l : scene.lights) while (res > 16 && light_map_work(scene.tri_verts.data(), ntri, l.pos, res) > work_cap) res /= 2;
         std::vector<float> all; all.reserve((size_t)6 * res * res * scene.lights.size());
         bool finite = true;
         for (size_t i = 0; i < scene.lights.size() && finite; ++i) {
