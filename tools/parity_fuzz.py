@@ -1,11 +1,14 @@
 """Randomised parity: random scene / size / seed / recursion setting / leaf size / semantics / camera moves / call sequence, the HIP
 path against the CPU oracle bit for bit (film sums, sums of squares, counts, packed pixels, ray counters).  Test infrastructure.
-usage: parity_fuzz.py [cases] [seed]   — prints one line per case, exits 1 on the first difference."""
+usage: [FUZZ_WILD=1] parity_fuzz.py [cases] [seed]   — prints one line per case, exits 1 on the first difference."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
+
+
+WILD = bool(os.environ.get("FUZZ_WILD"))
 
 
 def bits(a):
@@ -38,10 +41,15 @@ def one_case(pkg, O, scenes, rng, verbose=True):
     orc = O.Oracle(sc, w, h, tris_per_leaf=tpl, recursions=rec, spread=spread, seed=seed, flags=oflags)
     desc = "%s %dx%d seed %d rec %d spread %d tpl %d sem %d %s" % (name, w, h, seed, rec, spread, tpl, sem, stripes or "")
     steps = []
-    for _ in range(int(rng.integers(1, 5))):
+    for _ in range(int(rng.integers(1, 5)) + (1 if WILD else 0)):
         kind = rng.choice(["render", "frame", "move", "clear"], p=[0.4, 0.3, 0.2, 0.1])
+        if WILD and not steps:
+            kind = "move"                                   # FUZZ_WILD=1: every case starts with a wild camera move
         if kind == "move":
             dx, dy, dz = (float(x) for x in rng.normal(0, 0.4, 3)); ax, ay = float(rng.normal(0, 0.2)), float(rng.normal(0, 0.2))
+            if WILD or rng.random() < 0.3:                  # a wild move: into, through or behind the geometry, looking anywhere (triangles across the eye plane:
+                ext = float(np.ptp(sc["tri_verts"].reshape(-1, 3), axis=0).max())       # the screen-space structures must stand down, the tree walk answers)
+                dx, dy, dz = (float(x) for x in rng.normal(0, 0.5 * ext, 3)); ax, ay = float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-1.5, 1.5))
             rt.camera.move_rel(dx, dy, dz); orc.camera_move_rel(dx, dy, dz)
             rt.camera.add_x_angle(ax); orc.camera_add_x_angle(ax); rt.camera.add_y_angle(ay); orc.camera_add_y_angle(ay)
             rt.film.clear(); orc.film_clear()               # what the reference's binary does after a camera move (main.rs:116-169)
