@@ -335,6 +335,7 @@ Renderer::~Renderer()
 {
     if (hipSetDevice(cfg.device) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (read_stream_) (void)hipStreamSynchronize(read_stream_);          // nothing of this handle is in flight when its memory goes
     for (uint32_t i = 0; i < kMaxSlices; ++i) {
         if (i && slices_[i].stream) { (void)hipStreamSynchronize(slices_[i].stream); (void)hipStreamDestroy(slices_[i].stream); }
         if (slices_[i].done) (void)hipEventDestroy(slices_[i].done);
@@ -350,7 +351,7 @@ Renderer::~Renderer()
     comm_destroy();
     if (d_gather_) (void)hipFree(d_gather_);
     if (ev_tonemap_) (void)hipEventDestroy(ev_tonemap_);
-    if (read_stream_) { (void)hipStreamSynchronize(read_stream_); (void)hipStreamDestroy(read_stream_); }
+    if (read_stream_) (void)hipStreamDestroy(read_stream_);
     if (ev_call_done_) (void)hipEventDestroy(ev_call_done_);
     if (ev_spec_done_) (void)hipEventDestroy(ev_spec_done_);
     if (h_counters_spec_) (void)hipHostFree(h_counters_spec_);

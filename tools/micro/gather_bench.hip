@@ -7,6 +7,9 @@
 //   D  like A, but idle half of the lanes (odd) read node 0 (same address)
 //   E  like A, from LDS (the first 10 KB of the table staged per block)
 //   F  like A with 4 lanes of a quad on the SAME node (coherent quads)
+//   G  lane = ray, a 64-byte node (4-wide tree, half-precision boxes): FOUR dwordx4 loads of one half line
+//   H  lane = ray, a 64-byte node of which three quarters are read (THREE dwordx4)
+//   I  lane = ray, a 128-byte node (8-wide tree, quantised boxes): SIX dwordx4 loads of one line
 // Prints ns per node-visit per CU-cycle figures.  build: hipcc --offload-arch=gfx950 -O3 -o gather_bench gather_bench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -43,6 +46,10 @@ __global__ __launch_bounds__(256, 8) void gather(const uint4* __restrict__ table
         }
         else if (MODE == 3) { const uint32_t n = (lane & 1u) ? 0u : node; q0 = table[2 * n]; q1 = table[2 * n + 1]; }
         else if (MODE == 4) { const uint32_t n = node % ncache; q0 = s_nodes[2 * n]; q1 = s_nodes[2 * n + 1]; }
+        else if (MODE == 6) { const uint32_t n = node % (nnodes / 2u); q0 = table[4 * n]; q1 = table[4 * n + 1]; const uint4 q2 = table[4 * n + 2], q3 = table[4 * n + 3]; q0.w += q2.w; q1.w += q3.w; q0.x ^= q2.x; q1.y ^= q3.y; }
+        else if (MODE == 7) { const uint32_t n = node % (nnodes / 2u); q0 = table[4 * n]; q1 = table[4 * n + 1]; const uint4 q2 = table[4 * n + 2]; q0.w += q2.w; q0.x ^= q2.x; }
+        else if (MODE == 8) { const uint32_t n = node % (nnodes / 4u); q0 = table[8 * n]; q1 = table[8 * n + 1]; const uint4 q2 = table[8 * n + 2], q3 = table[8 * n + 3], q4 = table[8 * n + 4], q5 = table[8 * n + 5];
+                              q0.w += q2.w + q4.w; q1.w += q3.w + q5.w; q0.x ^= q2.x ^ q4.x; q1.y ^= q3.y ^ q5.y; }
         else { q0 = table[2 * node]; q1 = table[2 * node + 1]; }
         acc += q0.x ^ q1.y;
         node = (q0.w + q1.w + s * 40503u + ray) % nnodes;              // dependent: the next node comes from the data
@@ -64,9 +71,9 @@ int main(int argc, char** argv)
     const int cus = prop.multiProcessorCount;
     const dim3 grid(cus * 8), block(256);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const char* names[6] = { "A lane=ray, 2 x dwordx4", "B lane=ray, 1 x dwordx4", "C lane pair=ray, 1 x dwordx4 + DPP", "D as A, odd lanes read node 0", "E as A from LDS (320 nodes)", "F as A, quads share a node" };
+    const char* names[9] = { "A lane=ray, 2 x dwordx4", "B lane=ray, 1 x dwordx4", "C lane pair=ray, 1 x dwordx4 + DPP", "D as A, odd lanes read node 0", "E as A from LDS (320 nodes)", "F as A, quads share a node", "G 64-byte node, 4 x dwordx4", "H 64-byte node, 3 x dwordx4", "I 128-byte node, 6 x dwordx4" };
     for (int rep = 0; rep < 2; ++rep)
-    for (int m = 0; m < 6; ++m) {
+    for (int m = 0; m < 9; ++m) {
         CHECK(hipEventRecord(e0));
         const size_t lds = m == 4 ? 320 * 32 : 0;
         switch (m) {
@@ -75,7 +82,10 @@ int main(int argc, char** argv)
             case 2: hipLaunchKernelGGL(gather<2>, grid, block, lds, 0, d, nnodes, steps, out); break;
             case 3: hipLaunchKernelGGL(gather<3>, grid, block, lds, 0, d, nnodes, steps, out); break;
             case 4: hipLaunchKernelGGL(gather<4>, grid, block, lds, 0, d, nnodes, steps, out); break;
-            default: hipLaunchKernelGGL(gather<5>, grid, block, lds, 0, d, nnodes, steps, out); break;
+            case 5: hipLaunchKernelGGL(gather<5>, grid, block, lds, 0, d, nnodes, steps, out); break;
+            case 6: hipLaunchKernelGGL(gather<6>, grid, block, lds, 0, d, nnodes, steps, out); break;
+            case 7: hipLaunchKernelGGL(gather<7>, grid, block, lds, 0, d, nnodes, steps, out); break;
+            default: hipLaunchKernelGGL(gather<8>, grid, block, lds, 0, d, nnodes, steps, out); break;
         }
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
