@@ -353,4 +353,113 @@ void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, 
     out.root = 0;
 }
 
+// ---- the binary tree collapsed to 4-wide nodes of 48 bytes (bvh.hpp, BvhNode4) ---------------------------------------
+namespace {
+struct WideChild { int32_t ref; float mn[3], mx[3]; };
+float half_to_f32(uint32_t h) { _Float16 v; const uint16_t b = (uint16_t)h; std::memcpy(&v, &b, 2); return (float)v; }
+WideChild wide_child(const BvhNode& n, int c)
+{
+    WideChild w; const uint32_t* h = c ? n.h1 : n.h0;
+    w.ref = c ? n.child1 : n.child0;
+    for (int a = 0; a < 3; ++a) { w.mn[a] = half_to_f32(h[a] & 0xFFFFu); w.mx[a] = half_to_f32(h[a] >> 16); }
+    return w;
+}
+double wide_surface(const WideChild& w)
+{
+    const double dx = (double)w.mx[0] - w.mn[0], dy = (double)w.mx[1] - w.mn[1], dz = (double)w.mx[2] - w.mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+}  // namespace
+
+void build_wide(Bvh& b)
+{
+    b.nodes4.clear(); b.stack_need4 = 0;
+    if (b.root < 0 || b.nodes.empty() || b.max_leaf > 4 || b.tris.size() >= (1u << 20)) return;
+    std::vector<int32_t> bin_of(1, b.root);          // wide node -> the binary node it is rooted at; grows while it is walked (breadth-first)
+    std::vector<uint32_t> deferred(1, 0u);           // deferred children on the stack when the walk enters the node, at most
+    std::vector<BvhNode4> out;
+    std::vector<BvhTri> tris; tris.reserve(b.tris.size());
+    std::vector<uint32_t> new_first(b.tris.size(), 0xFFFFFFFFu);
+    uint32_t need = 0;
+    for (size_t w = 0; w < bin_of.size(); ++w) {
+        const BvhNode& n = b.nodes[bin_of[w]];
+        WideChild c[4]; int k = 2;
+        c[0] = wide_child(n, 0); c[1] = wide_child(n, 1);
+        while (k < 4) {                               // open the inner child with the largest surface
+            int best = -1; double bs = -1.0;
+            for (int i = 0; i < k; ++i) if (c[i].ref >= 0 && wide_surface(c[i]) > bs) { bs = wide_surface(c[i]); best = i; }
+            if (best < 0) break;
+            const BvhNode& m = b.nodes[c[best].ref];
+            c[best] = wide_child(m, 0); c[k++] = wide_child(m, 1);
+        }
+        BvhNode4 o; std::memset(&o, 0, sizeof o);
+        const uint32_t child_base = (uint32_t)bin_of.size(), tri_base = (uint32_t)tris.size();
+        double org[3], scale[3]; uint32_t eb[3];
+        for (int a = 0; a < 3; ++a) {
+            float lo = c[0].mn[a], hi = c[0].mx[a];
+            for (int i = 1; i < k; ++i) { lo = std::min(lo, c[i].mn[a]); hi = std::max(hi, c[i].mx[a]); }
+            if (!(std::fabs(lo) < 3e38f) || !(std::fabs(hi) < 3e38f)) return;                 // a coordinate beyond the half range (+-inf): binary nodes only
+            const double ext = (double)hi - (double)lo;
+            int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+            e = std::max(e, -100);
+            while (std::ldexp(255.0, e) < ext) ++e;
+            if (e > 100) return;
+            o.org[a] = lo; org[a] = lo; scale[a] = std::ldexp(1.0, e); eb[a] = (uint32_t)(e + 127);
+        }
+        uint32_t lo_w[3] = { 0, 0, 0 }, hi_w[3] = { 0, 0, 0 }, meta = 0, ninner = 0;
+        for (int i = 0; i < 4; ++i) {
+            uint32_t mb = 0;
+            for (int a = 0; a < 3; ++a) {
+                uint32_t ql = 255u, qh = 0u;                                                  // unused slot: inverted box
+                if (i < k) {
+                    const double fl = std::floor(((double)c[i].mn[a] - org[a]) / scale[a]), fh = std::ceil(((double)c[i].mx[a] - org[a]) / scale[a]);
+                    ql = (uint32_t)std::min(255.0, std::max(0.0, fl)); qh = (uint32_t)std::min(255.0, std::max(0.0, fh));
+                    if (org[a] + ql * scale[a] > (double)c[i].mn[a] || org[a] + qh * scale[a] < (double)c[i].mx[a]) return;   // cannot happen (e is chosen so that 255 steps span the node)
+                }
+                lo_w[a] |= ql << (8 * i); hi_w[a] |= qh << (8 * i);
+            }
+            if (i < k && c[i].ref >= 0) {
+                mb = 0x80u | ninner++;
+                bin_of.push_back(c[i].ref); deferred.push_back(deferred[w] + (uint32_t)k - 1u);
+            } else if (i < k) {
+                const uint32_t code = ~(uint32_t)c[i].ref, first = code >> 3, cnt = (code & 7u) + 1u;
+                const uint32_t at = (uint32_t)tris.size();
+                for (uint32_t t = 0; t < cnt; ++t) tris.push_back(b.tris[first + t]);
+                new_first[first] = at;
+                mb = ((at - tri_base) << 3) | (cnt - 1u);                                      // <= 12 << 3 | 3
+            }
+            meta |= mb << (8 * i);
+        }
+        need = std::max(need, deferred[w] + (uint32_t)k - 1u);
+        if (child_base + ninner >= (1u << 20) || tris.size() >= (1u << 20)) return;
+        o.ew = eb[0] | eb[1] << 8 | eb[2] << 16 | ((tri_base >> 12) & 0xFFu) << 24;
+        o.lox = lo_w[0]; o.hix = hi_w[0]; o.loy = lo_w[1]; o.hiy = hi_w[1]; o.loz = lo_w[2]; o.hiz = hi_w[2];
+        o.meta = meta; o.bases = child_base | (tri_base & 0xFFFu) << 20;
+        out.push_back(o);
+        {   // what the kernels decode from these words (traverse.hpp, wide_children) must be the children collected above
+            const uint32_t cbm = (o.bases & 0xFFFFFu) - 128u, nb = ~(((o.bases >> 20) | ((o.ew >> 24) << 12)) << 3);
+            uint32_t inner_seen = 0;
+            for (int i = 0; i < k; ++i) {
+                const uint32_t t = (o.meta >> (8 * i)) & 0xFFu;
+                const int32_t ref = (t & 0x80u) ? (int32_t)(cbm + t) : (int32_t)(nb - t);
+                if (c[i].ref >= 0) { if (ref != (int32_t)(child_base + inner_seen) || bin_of[child_base + inner_seen] != c[i].ref) return; ++inner_seen; }
+                else {
+                    const uint32_t code = ~(uint32_t)c[i].ref, cnt = (code & 7u) + 1u, ncode = ~(uint32_t)ref;
+                    if (ref >= 0 || (ncode & 7u) + 1u != cnt || (ncode >> 3) + cnt > tris.size() || new_first[code >> 3] != (ncode >> 3)) return;
+                }
+            }
+        }
+    }
+    if (tris.size() != b.tris.size()) return;                                                 // every leaf hangs under exactly one wide node
+    // commit: the triangles in the wide tree's order, the binary leaves re-pointed at them
+    for (BvhNode& n : b.nodes)
+        for (int32_t* ch : { &n.child0, &n.child1 })
+            if (*ch < 0) { const uint32_t code = ~(uint32_t)*ch, first = code >> 3, cnt = (code & 7u) + 1u; if (first < new_first.size() && new_first[first] != 0xFFFFFFFFu) *ch = leaf_code(new_first[first], cnt); }
+    // (the leaf byte of an unused slot points at triangle tri_base, which exists: only a ray with a null direction passes the inverted box, and it can hit nothing)
+    b.tris.swap(tris);
+    b.nodes4.swap(out);
+    b.stack_need4 = need;
+    if (std::getenv("MI355RT_DEBUG_BVH")) fprintf(stderr, "[mi355rt] wide BVH: %zu nodes of 4 (binary: %zu), stack need %u (binary depth %u)\n", b.nodes4.size(), b.nodes.size(), b.stack_need4, b.max_depth);
+}
+
 }  // namespace mi355rt

@@ -26,8 +26,23 @@ static_assert(sizeof(BvhNode) == 32, "node must be 32 bytes");
 struct alignas(16) BvhTri { float v0[3]; uint32_t prim; float e1[3]; uint32_t geom; float e2[3]; uint32_t pad; };
 static_assert(sizeof(BvhTri) == 48, "triangle must be 48 bytes");
 
+// 4-wide node in 48 bytes (three 16-byte loads; the slot is 64 bytes so that no node straddles a 128-byte line).  The gather microbenchmark
+// (tools/micro/gather_bench.hip) prices three loads of a 64-byte slot at 1.23 binary-node visits, and a 4-wide tree needs ~0.55 of the visits.
+// The four child boxes are 8-bit offsets in a per-node frame (Ylitie, Karras, Laine 2017): plane = org[a] + q * 2^(e[a] - 127), minima rounded
+// down and maxima up from the (already padded, already outward-rounded) half-precision boxes of the binary tree they are collapsed from.
+//   q0 = { org.x, org.y, org.z, ex | ey << 8 | ez << 16 | tri_base[19:12] << 24 }
+//   q1 = { lo.x[4], hi.x[4], lo.y[4], hi.y[4] }          (byte i = child i)
+//   q2 = { lo.z[4], hi.z[4], meta[4], child_base | tri_base[11:0] << 20 }
+//   meta byte of an inner child: 0x80 | its place among the node's inner children — they sit at child_base, child_base + 1, ...;
+//   of a leaf child: (first triangle - tri_base) << 3 | count - 1 — the node's leaf triangles sit together from tri_base on (leaves of <= 4);
+//   an unused slot: an inverted box (lo 255, hi 0) and a leaf byte of 0 (a ray with a null direction passes every box and can hit no triangle).
+struct alignas(16) BvhNode4 { float org[3]; uint32_t ew; uint32_t lox, hix, loy, hiy; uint32_t loz, hiz, meta, bases; uint32_t pad[4]; };
+static_assert(sizeof(BvhNode4) == 64, "wide node slot must be 64 bytes");
+
 struct Bvh {
     std::vector<BvhNode> nodes;      // breadth-first: the top of the tree has the lowest indices
+    std::vector<BvhNode4> nodes4;    // the same tree collapsed to 4-wide nodes (build_wide); empty when it does not apply
+    uint32_t stack_need4 = 0;        // most deferred children any root-to-leaf walk of the wide tree can hold
     std::vector<BvhTri> tris;        // leaf order
     int32_t root = 0;                // node index, or a leaf code when the scene is a single leaf
     uint32_t leaves = 0, max_depth = 0, max_leaf = 0;
@@ -39,6 +54,10 @@ constexpr uint32_t kBvhMaxLeaf = 4;
 
 // tri_verts: ntri*9 world-space floats, tri_geom: ntri geometry indices.
 void build_bvh(const float* tri_verts, const uint32_t* tri_geom, uint32_t ntri, Bvh& out);
+
+// Collapses b.nodes into b.nodes4 (re-orders b.tris so that the leaves under one wide node lie together, and re-points the binary leaves).
+// Leaves nodes4 empty when the format does not apply (leaves of more than 4 triangles, 2^20 nodes or triangles and beyond, a single-leaf scene).
+void build_wide(Bvh& b);
 
 // The same structure built on the current HIP device (lbvh.hip: Morton order, Karras hierarchy, refit; MI355RT_FLAG_DEVICE_LBVH).
 // false + `why`: the device path does not serve this scene (the caller builds on the host).  ms[0] device time, ms[1] wall time.

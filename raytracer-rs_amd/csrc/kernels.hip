@@ -53,6 +53,9 @@ constexpr uint32_t kMiss = 0xFFFFFFFFu;
 #ifndef MI355RT_PRIMARY_BLOCKS
 #define MI355RT_PRIMARY_BLOCKS 7                // blocks per CU the primary trace kernel is compiled for: 69 VGPRs; 8 blocks = 64 VGPRs + 20 B of scratch, measured in profiles/r03_notes.md
 #endif
+#ifndef MI355RT_WIDE_BLOCKS
+#define MI355RT_WIDE_BLOCKS 5                   // blocks per CU the trace kernels are compiled for when they walk the 4-wide tree (deeper stacks: ~32 LDS rows per block)
+#endif
 #ifndef MI355RT_CONFIRM_BLOCKS
 #define MI355RT_CONFIRM_BLOCKS 5               // blocks per CU the confirm kernel is compiled for (A/B knob, profiles/r02_notes.md)
 #endif
@@ -579,7 +582,7 @@ __device__ __forceinline__ void trace_wave(const DScene& sc, const DCamera& cam,
 }
 
 template <bool PRIMARY, bool COUNT, bool CONFIRM>
-__global__ __launch_bounds__(kBlock, PRIMARY ? MI355RT_PRIMARY_BLOCKS : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
+__global__ __launch_bounds__(kBlock, MI355RT_WIDE ? MI355RT_WIDE_BLOCKS : PRIMARY ? MI355RT_PRIMARY_BLOCKS : 8) void trace_kernel(DScene sc, DCamera cam, DPass ps,
                                                       const float4* __restrict__ in_q, const uint2* __restrict__ in_counts,
                                                       float4* __restrict__ hits, uint32_t* cursor,
                                                       float* __restrict__ slot_L, const uint32_t* __restrict__ film_n,
@@ -1478,6 +1481,8 @@ hipError_t launch_numerics(hipStream_t stream, const float* a, const float* b, u
 }
 
 // ---- launchers --------------------------------------------------------------------------------
+bool kernels_walk_wide_nodes() { return MI355RT_WIDE != 0; }
+
 static size_t stack_bytes(uint32_t depth) { return (size_t)((depth ? depth : 1u) + 1u) * kBlock * sizeof(int); }   // sentinel row + one row per level (the deepest level's row doubles as the spare row above the top)
 
 template <bool P, bool C, bool F>

@@ -22,6 +22,7 @@ hipError_t launch_shade(hipStream_t stream, int num_cus, bool primary, bool walk
 hipError_t launch_resolve(hipStream_t stream, const DPass& ps, uint32_t width, uint32_t nlights, const float* slot_L, const uint32_t* sample_slot,
                           float* film_sum, float* film_sumsq, uint32_t* film_n, float* debug_color, uint32_t* ctrl);   // ctrl != null: zero the pass's work cursors on the way out
 // one 50-row frame (1 sample per pixel) in a single launch: every wave takes a 64-sample chunk through all rounds
+bool kernels_walk_wide_nodes();      // this build's trace loops read BvhNode4 slots (MI355RT_WIDE), not BvhNode
 uint32_t fused_pass_lds_rows(uint32_t stack_depth, uint32_t max_level_nodes, uint32_t records_per_sample);
 // reference-default semantics: true closest hits of a round -> the octree intersector's answers (+ the shadow predicate)
 hipError_t launch_confirm(hipStream_t stream, int num_cus, bool primary, bool shadow_only, const DScene& sc, const DCamera& cam, const DPass& ps,

@@ -156,6 +156,12 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     }
     if (!on_device) build_bvh(scene.tri_verts.data(), scene.tri_geom.data(), ntri, bvh);
     bvh_on_device_ = on_device;
+    wide_ = false;
+    if (kernels_walk_wide_nodes()) {
+        build_wide(bvh);
+        if (!bvh.nodes4.empty()) wide_ = true;
+        else if (bvh.root >= 0) { err = "this build's kernels walk the 4-wide tree, which does not serve this scene"; code = MI355RT_E_INVALID; return false; }
+    }
     build_ms_[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bvh).count();
     collect_cull_boxes();
     if (bvh.max_depth > kBvhMaxDepth) { err = "internal: BVH deeper than the traversal stack"; code = MI355RT_E_INVALID; return false; }
@@ -173,7 +179,7 @@ bool Renderer::init(const SceneData& scene, std::string& err, int& code)
     // --- uploads
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_normals = nullptr; void* d_table = nullptr;
     DMaterial* d_mats = nullptr; DLight* d_lights = nullptr; DTexture* d_tex = nullptr; float* d_texels = nullptr;
-    if (!upload(d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode))) return bail();
+    if (wide_ ? !upload(d_nodes, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(BvhNode4)) : !upload(d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode))) return bail();
     if (!upload(d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri))) return bail();
     if (!upload(d_normals, normals.data(), normals.size() * sizeof(float))) return bail();
     if (!upload(d_table, table4.data(), table4.size() * sizeof(float))) return bail();
@@ -759,7 +765,7 @@ void Renderer::describe_pass(DPass& ps, const Slice& sl, const uint32_t* d_rows,
     ps.use_explicit = explicit_sample ? 1u : 0u; ps.explicit_pixel = epixel; ps.explicit_sampleno = esample;
     ps.chunk = chunk; ps.nchunks = (uint32_t)((nsamples + chunk - 1) / chunk); ps.region = chunk * records_per_sample_;
     ps.hit_prim = sl.d_hit_prim; ps.qstride = sl.queue_records; ps.slot_ps = (uint2*)sl.d_slot_ps;
-    ps.stack_depth = bvh.max_depth + 1; ps.list_cap = chunk * max_level_nodes_;
+    ps.stack_depth = traversal_rows(); ps.list_cap = chunk * max_level_nodes_;
     ps.leaf_threshold = leaf_threshold_;
     ps.refill_threshold = 24; if (const char* e = getenv("MI355RT_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ps.refill_threshold = (uint32_t)v; }
     // the primary launch refills later: its rays are neighbours on the screen, and the more of them start together the more lanes of a quad
@@ -1057,7 +1063,7 @@ uint32_t Renderer::trace_frame_additive()
     const FrameWindow win = frame_window(current_row, cfg.height, cfg.stripe_rows, cfg.stripe_world, cfg.stripe_rank, owned_rows);
     // instrumented / timed / reference-exact-octree calls go through the wavefront rounds (several launches, waits for the device)
     const bool wavefront = (cfg.flags & MI355RT_FLAG_COUNT_STEPS) != 0 || mode_ == kModeOctreeWalk
-                           || fused_pass_lds_rows(bvh.max_depth + 1, max_level_nodes_, records_per_sample_) > 60u || getenv("MI355RT_NO_FUSED");
+                           || fused_pass_lds_rows(traversal_rows(), max_level_nodes_, records_per_sample_) > 60u || getenv("MI355RT_NO_FUSED");
     if (wavefront) {
         if (!begin_call()) return 0;
         for (uint32_t done = 0; done < win.total; done += nown) {
@@ -1420,7 +1426,7 @@ bool Renderer::intersect(const float* rays6, size_t n, float* tuv, uint32_t* pri
     chk(hipMalloc((void**)&d_blocked, n), "hipMalloc blocked");
     if (ok) chk(hipMemcpyAsync(d_rays, rays6, n * 24, hipMemcpyHostToDevice, stream_), "upload rays");
     if (ok && !shadow) chk(hipMemcpyAsync(d_tuv, tuv, n * 12, hipMemcpyHostToDevice, stream_), "upload tuv");   // misses stay untouched
-    if (ok) chk(launch_intersect(stream_, dscene_, bvh.max_depth + 1, mode_ == kModeConfirm ? 0 : mode_ == kModeOctreeWalk ? 1 : 2, d_rays, (uint32_t)n, shadow, d_tuv, d_prim, d_blocked), "intersect kernel");
+    if (ok) chk(launch_intersect(stream_, dscene_, traversal_rows(), mode_ == kModeConfirm ? 0 : mode_ == kModeOctreeWalk ? 1 : 2, d_rays, (uint32_t)n, shadow, d_tuv, d_prim, d_blocked), "intersect kernel");
     if (ok && shadow) chk(hipMemcpyAsync(blocked, d_blocked, n, hipMemcpyDeviceToHost, stream_), "download blocked");
     if (ok && !shadow) {
         chk(hipMemcpyAsync(tuv, d_tuv, n * 12, hipMemcpyDeviceToHost, stream_), "download tuv");

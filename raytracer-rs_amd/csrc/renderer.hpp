@@ -83,6 +83,8 @@ public:
     double build_ms_[2] = { 0.0, 0.0 };   // build times inside create (wall): BVH (host binned SAH, or the device build), octree (SAT, host)
     double light_map_ms_ = 0.0;           // build time of the lights' depth cube maps inside create
     bool bvh_on_device_ = false;          // MI355RT_FLAG_DEVICE_LBVH and the device build served the scene
+    bool wide_ = false;                   // the device holds the 4-wide tree (bvh.nodes4): this build's kernels walk it
+    uint32_t traversal_rows() const { return (wide_ ? bvh.stack_need4 : bvh.max_depth) + 1u; }       // stack rows the trace loops need (kernels.hip, stack_bytes)
     double lbvh_device_ms_ = 0.0;         // its device time (kernels + sort)
     enum Mode { kModeConfirm = 0, kModeOctreeWalk = 1, kModeTrueClosest = 2 };
     Mode mode_ = kModeConfirm;            // intersector semantics, fixed at creation

@@ -12,6 +12,10 @@
 #include "device_math.hpp"
 #include "device_types.hpp"
 
+#ifndef MI355RT_WIDE
+#define MI355RT_WIDE 0                       // 1: the kernels walk the 4-wide tree of 48-byte nodes (bvh.hpp, BvhNode4) instead of the binary one
+#endif
+
 namespace mi355rt {
 
 struct RayState {
@@ -43,9 +47,16 @@ __device__ __forceinline__ void ray_init(RayState& s, f3 o, f3 d, bool shadow, i
     const bool null_dir = !(dmax > 0.0f);
     s.idx = null_dir ? 0.0f : __builtin_amdgcn_rcpf(bx); s.idy = null_dir ? 0.0f : __builtin_amdgcn_rcpf(by); s.idz = null_dir ? 0.0f : __builtin_amdgcn_rcpf(bz);
     s.oidx = -(o.x * s.idx); s.oidy = -(o.y * s.idy); s.oidz = -(o.z * s.idz);
+#if MI355RT_WIDE
+    // v_perm(hi, lo, sel): the dword of the four children's NEAR planes on this axis (lo bytes, or hi bytes when d' < 0); sel ^ 0x04040404 takes the far ones
+    s.selx = __builtin_signbitf(bx) ? 0x07060504u : 0x03020100u;
+    s.sely = __builtin_signbitf(by) ? 0x07060504u : 0x03020100u;
+    s.selz = __builtin_signbitf(bz) ? 0x07060504u : 0x03020100u;
+#else
     s.selx = __builtin_signbitf(bx) ? 0x01000302u : 0x03020100u;
     s.sely = __builtin_signbitf(by) ? 0x01000302u : 0x03020100u;
     s.selz = __builtin_signbitf(bz) ? 0x01000302u : 0x03020100u;
+#endif
     s.tlimit = shadow ? 0x1.fffffep-1f : __builtin_inff();     // shadow: t < 1.0
     s.t = __builtin_inff(); s.u = 0.0f; s.v = 0.0f; s.prim = 0xFFFFFFFFu;
     s.node = root; s.tri = 0u; s.sp = 0; s.occ = shadow ? 0 : -1; s.shadow = shadow;
@@ -72,6 +83,45 @@ __device__ __forceinline__ void slab_child(const uint4 q, const RayState& s, flo
     tf = fminf(fminf(fx, fy), fminf(fz, s.tlimit));
 }
 
+#if MI355RT_WIDE
+// The four children of a 48-byte node (bvh.hpp, BvhNode4): slab distances from the 8-bit planes, t = q * (2^e / d) + (org - o) / d — like slab_child
+// not the reference's expression and not required to be (the boxes are padded and rounded outward on the host) —, and the children's references
+// in the binary tree's own encoding (>= 0 node index, < 0 leaf code).
+__device__ __forceinline__ float wide_byte(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xFFu); }        // v_cvt_f32_ubyte<i>
+__device__ __forceinline__ void wide_children(const uint4 q0, const uint4 q1, const uint4 q2, const RayState& s, float tn[4], bool h[4], int ref[4])
+{
+    const float sx = __uint_as_float((q0.w & 0xFFu) << 23) * s.idx, sy = __uint_as_float(((q0.w >> 8) & 0xFFu) << 23) * s.idy, sz = __uint_as_float(((q0.w >> 16) & 0xFFu) << 23) * s.idz;
+    const float bx = __builtin_fmaf(__uint_as_float(q0.x), s.idx, s.oidx), by = __builtin_fmaf(__uint_as_float(q0.y), s.idy, s.oidy), bz = __builtin_fmaf(__uint_as_float(q0.z), s.idz, s.oidz);
+    const uint32_t nxw = __builtin_amdgcn_perm(q1.y, q1.x, s.selx), fxw = __builtin_amdgcn_perm(q1.y, q1.x, s.selx ^ 0x04040404u);
+    const uint32_t nyw = __builtin_amdgcn_perm(q1.w, q1.z, s.sely), fyw = __builtin_amdgcn_perm(q1.w, q1.z, s.sely ^ 0x04040404u);
+    const uint32_t nzw = __builtin_amdgcn_perm(q2.y, q2.x, s.selz), fzw = __builtin_amdgcn_perm(q2.y, q2.x, s.selz ^ 0x04040404u);
+    const uint32_t cbm = (q2.w & 0xFFFFFu) - 128u;                                  // inner child: child_base + (byte - 0x80)
+    const uint32_t nb = ~(((q2.w >> 20) | ((q0.w >> 24) << 12)) << 3);             // leaf child: ~((tri_base << 3) + byte) = nb - byte
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float nx = __builtin_fmaf(wide_byte(nxw, i), sx, bx), fx = __builtin_fmaf(wide_byte(fxw, i), sx, bx);
+        const float ny = __builtin_fmaf(wide_byte(nyw, i), sy, by), fy = __builtin_fmaf(wide_byte(fyw, i), sy, by);
+        const float nz = __builtin_fmaf(wide_byte(nzw, i), sz, bz), fz = __builtin_fmaf(wide_byte(fzw, i), sz, bz);
+        tn[i] = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+        const float tf = fminf(fminf(fx, fy), fminf(fz, s.tlimit));
+        h[i] = tn[i] <= tf;
+        const uint32_t t = (q2.z >> (8 * i)) & 0xFFu;
+        ref[i] = (t & 0x80u) ? (int)(cbm + t) : (int)(nb - t);
+    }
+}
+// the nearest of the children that were hit: slot and reference (anything when none was)
+__device__ __forceinline__ void wide_nearest(const float tn[4], const bool h[4], const int ref[4], int& near, int& near_ref)
+{
+    const float inf = __builtin_inff();
+    const float k0 = h[0] ? tn[0] : inf, k1 = h[1] ? tn[1] : inf, k2 = h[2] ? tn[2] : inf, k3 = h[3] ? tn[3] : inf;
+    const bool b1 = k1 < k0, b3 = k3 < k2;
+    const float m01 = b1 ? k1 : k0, m23 = b3 ? k3 : k2;
+    const bool bb = m23 < m01;
+    near = bb ? (b3 ? 3 : 2) : (b1 ? 1 : 0);
+    near_ref = bb ? (b3 ? ref[3] : ref[2]) : (b1 ? ref[1] : ref[0]);
+}
+#endif
+
 // Pop the next deferred node; returns true when the stack is empty (ray finished).
 __device__ __forceinline__ bool ray_pop(RayState& s, const int* stack, int stride)
 {
@@ -90,6 +140,20 @@ __device__ __forceinline__ bool inner_step(const DScene& sc, RayState& s, int* s
 {
     const uint4* __restrict__ nodes = (const uint4*)sc.nodes;
     if (COUNT) ++n_nodes;
+#if MI355RT_WIDE
+    {
+        const uint4 w0 = nodes[4 * s.node], w1 = nodes[4 * s.node + 1], w2 = nodes[4 * s.node + 2];
+        float tn[4]; bool h[4]; int ref[4]; int near, near_ref;
+        wide_children(w0, w1, w2, s, tn, h, ref);
+        wide_nearest(tn, h, ref, near, near_ref);
+        s.tri = 0u;
+        if (!(h[0] | h[1] | h[2] | h[3])) return ray_pop(s, stack, stride);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (h[i] && i != near) { stack[s.sp * stride] = ref[i]; ++s.sp; }
+        s.node = near_ref;
+        return false;
+    }
+#endif
     const uint4 q0 = nodes[2 * s.node], q1 = nodes[2 * s.node + 1];
     float tn0, tf0, tn1, tf1;
     slab_child(q0, s, tn0, tf0);
@@ -197,6 +261,28 @@ __device__ __forceinline__ void inner_pred(const DScene& sc, RayState& s, int* s
         n_nodes += pred ? 1u : 0u;
         if (below) for (int k = 0; k < 6; ++k) below[k] += (pred && s.node < (64 << k)) ? 1u : 0u;      // what an LDS copy of the first 64 .. 2048 nodes would serve (profiles/r03_notes.md)
     }
+#if MI355RT_WIDE
+    {
+        const uint32_t woff = pred ? (uint32_t)s.node << 6 : 0u;      // 64-byte slots, 48 bytes read
+        const char* __restrict__ wbase = (const char*)sc.nodes;
+        const uint4 w0 = *(const uint4*)(wbase + woff), w1 = *(const uint4*)(wbase + woff + 16u), w2 = *(const uint4*)(wbase + woff + 32u);
+        float tn[4]; bool h[4]; int ref[4]; int near, near_ref;
+        wide_children(w0, w1, w2, s, tn, h, ref);
+        wide_nearest(tn, h, ref, near, near_ref);
+        const bool none = pred & !(h[0] | h[1] | h[2] | h[3]);
+        // the other hit children, pushed in slot order; a lane that does not push writes the row above its top (free space: one spare row)
+        int sp = s.sp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            stack[(sp + 1) * stride] = ref[i];
+            sp += (pred & h[i] & (near != i)) ? 1 : 0;
+        }
+        s.sp = sp;
+        const int next = pop_or_finish(s, none, stack, stride);
+        s.node = pred ? (none ? next : near_ref) : s.node;
+        return;
+    }
+#endif
     const uint32_t off = pred ? (uint32_t)s.node << 5 : 0u;           // 32-byte nodes, unsigned 32-bit byte offset
     const char* __restrict__ base = (const char*)sc.nodes;
     const uint4 q0 = *(const uint4*)(base + off), q1 = *(const uint4*)(base + off + 16u);
