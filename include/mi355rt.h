@@ -256,6 +256,14 @@ int mi355rt_debug_speculation(const mi355rt_handle* h, uint64_t out[2]);
  * distance to the nearest triangle.  Exists so that the bound can be checked against brute force without a GPU. */
 int mi355rt_debug_light_map(const float* tri_verts, uint32_t ntri, const float light[3], double pad, uint32_t res, float* out_dist2, double* nearest);
 
+/* Test hook (host only, no device): the 4-wide tree of 48-byte nodes that experiment builds of the kernels walk (-DMI355RT_WIDE=1; bvh.hpp,
+ * BvhNode4: 8-bit child boxes in a per-node frame), built from the ntri triangles like mi355rt_create builds the binary tree, then checked by a
+ * walk that decodes the node words the way the kernels do.  out[0] wide nodes (0: the format does not serve this scene), [1] binary nodes,
+ * [2] most deferred children of any walk (stack rows), [3] binary depth, [4] child slots in use, [5] triangles the walk of the wide tree reaches
+ * exactly once, [6] child boxes that fail to contain a vertex of a triangle below them (must be 0), [7] triangles the re-pointed binary tree
+ * reaches exactly once. */
+int mi355rt_debug_wide_bvh(const float* tri_verts, uint32_t ntri, uint32_t out[8]);
+
 /* acceleration-structure facts: out[0] nodes, [1] leaves, [2] max depth, [3] max leaf size,
  * [4] node bytes, [5] triangle bytes, [6] BVH build time inside create (wall, microseconds; host SAH build, or the device
  * build with its uploads and read-back), [7] host octree build time inside create (microseconds; 0 with

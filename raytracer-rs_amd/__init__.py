@@ -133,6 +133,7 @@ ABI = [
     ("mi355rt_tree_nodes", C.c_uint32, [_H]),
     ("mi355rt_debug_speculation", C.c_int, [_H, C.POINTER(C.c_uint64)]),
     ("mi355rt_debug_light_map", C.c_int, [_F, C.c_uint32, _F, C.c_double, C.c_uint32, _F, C.POINTER(C.c_double)]),
+    ("mi355rt_debug_wide_bvh", C.c_int, [_F, C.c_uint32, _U]),
     ("mi355rt_accel_stats", C.c_int, [_H, _U]),
     ("mi355rt_octree_stats", C.c_int, [_H, _U]),
     ("mi355rt_bvh_build_info", C.c_int, [_H, _U]),
@@ -529,6 +530,17 @@ def debug_light_map(tri_verts, light, pad, res):
     if code != 0:
         raise RuntimeError("mi355rt_debug_light_map failed: %d" % code)
     return out, nearest.value
+
+
+def debug_wide_bvh(tri_verts):
+    """facts about the 4-wide tree of 48-byte nodes the MI355RT_WIDE experiment builds walk, checked by a host walk (include/mi355rt.h)"""
+    v = np.ascontiguousarray(tri_verts, np.float32).reshape(-1, 9)
+    out = (C.c_uint32 * 8)()
+    code = lib().mi355rt_debug_wide_bvh(_fp(v), v.shape[0], out)
+    if code != 0:
+        raise RuntimeError("mi355rt_debug_wide_bvh failed: %d" % code)
+    keys = ("wide_nodes", "binary_nodes", "stack_need", "binary_depth", "children", "tris_once_wide", "bad_boxes", "tris_once_binary")
+    return dict(zip(keys, (int(x) for x in out)))
 
 
 def comm_unique_id():

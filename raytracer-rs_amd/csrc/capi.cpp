@@ -294,6 +294,73 @@ int mi355rt_debug_light_map(const float* tri_verts, uint32_t ntri, const float l
     return MI355RT_OK;
 }
 
+namespace {
+// bounds of every vertex below a reference of the wide tree; counts what the walk reaches and which child boxes fail to hold their subtree
+struct WideWalk {
+    const mi355rt::Bvh& b; std::vector<uint32_t> seen; uint32_t children = 0, bad_boxes = 0;
+    void below(int32_t ref, double mn[3], double mx[3])
+    {
+        for (int a = 0; a < 3; ++a) { mn[a] = 1e300; mx[a] = -1e300; }
+        if (ref < 0) {
+            const uint32_t code = ~(uint32_t)ref, first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t t = first; t < first + cnt && t < b.tris.size(); ++t) {
+                const mi355rt::BvhTri& r = b.tris[t];
+                if (r.prim < seen.size()) ++seen[r.prim];
+                for (int v = 0; v < 3; ++v) for (int a = 0; a < 3; ++a) {
+                    const double x = (double)r.v0[a] + (v == 1 ? (double)r.e1[a] : v == 2 ? (double)r.e2[a] : 0.0);
+                    mn[a] = std::min(mn[a], x); mx[a] = std::max(mx[a], x);
+                }
+            }
+            return;
+        }
+        const mi355rt::BvhNode4& o = b.nodes4[(size_t)ref];
+        const uint32_t cbm = (o.bases & 0xFFFFFu) - 128u, nb = ~(((o.bases >> 20) | ((o.ew >> 24) << 12)) << 3);      // traverse.hpp, wide_children
+        const uint32_t lo[3] = { o.lox, o.loy, o.loz }, hi[3] = { o.hix, o.hiy, o.hiz };
+        for (int i = 0; i < 4; ++i) {
+            if (((lo[0] >> (8 * i)) & 0xFFu) > ((hi[0] >> (8 * i)) & 0xFFu)) continue;                                  // unused slot (inverted box)
+            ++children;
+            const uint32_t t = (o.meta >> (8 * i)) & 0xFFu;
+            const int32_t cref = (t & 0x80u) ? (int32_t)(cbm + t) : (int32_t)(nb - t);
+            double cmn[3], cmx[3];
+            below(cref, cmn, cmx);
+            for (int a = 0; a < 3; ++a) {
+                const double scale = std::ldexp(1.0, (int)((o.ew >> (8 * a)) & 0xFFu) - 127);
+                const double blo = (double)o.org[a] + (double)((lo[a] >> (8 * i)) & 0xFFu) * scale, bhi = (double)o.org[a] + (double)((hi[a] >> (8 * i)) & 0xFFu) * scale;
+                if (cmn[a] <= cmx[a] && (blo > cmn[a] || bhi < cmx[a])) { ++bad_boxes; break; }
+                mn[a] = std::min(mn[a], cmn[a]); mx[a] = std::max(mx[a], cmx[a]);
+            }
+        }
+    }
+};
+}  // namespace
+
+int mi355rt_debug_wide_bvh(const float* tri_verts, uint32_t ntri, uint32_t out[8])
+{
+    if ((ntri && !tri_verts) || !out) return MI355RT_E_INVALID;
+    std::vector<uint32_t> geom(std::max(ntri, 1u), 0u);
+    mi355rt::Bvh b;
+    mi355rt::build_bvh(tri_verts, geom.data(), ntri, b);
+    mi355rt::build_wide(b);
+    for (int k = 0; k < 8; ++k) out[k] = 0u;
+    out[1] = (uint32_t)b.nodes.size(); out[3] = b.max_depth;
+    if (b.nodes4.empty()) return MI355RT_OK;
+    out[0] = (uint32_t)b.nodes4.size(); out[2] = b.stack_need4;
+    WideWalk w{ b, std::vector<uint32_t>(ntri, 0u) };
+    double mn[3], mx[3];
+    w.below(0, mn, mx);
+    out[4] = w.children; out[6] = w.bad_boxes;
+    for (uint32_t c : w.seen) out[5] += c == 1u ? 1u : 0u;
+    std::vector<uint32_t> seen2(ntri, 0u);
+    std::vector<int32_t> st(1, b.root);
+    while (!st.empty()) {
+        const int32_t r = st.back(); st.pop_back();
+        if (r < 0) { const uint32_t code = ~(uint32_t)r, first = code >> 3, cnt = (code & 7u) + 1u; for (uint32_t t = first; t < first + cnt && t < b.tris.size(); ++t) if (b.tris[t].prim < ntri) ++seen2[b.tris[t].prim]; }
+        else { st.push_back(b.nodes[(size_t)r].child0); st.push_back(b.nodes[(size_t)r].child1); }
+    }
+    for (uint32_t c : seen2) out[7] += c == 1u ? 1u : 0u;
+    return MI355RT_OK;
+}
+
 int mi355rt_accel_stats(const mi355rt_handle* h, uint32_t out[8])
 {
     if (!h || !out) return MI355RT_E_INVALID;
