@@ -1,6 +1,6 @@
 """Randomised parity: random scene / size / seed / recursion setting / leaf size / semantics / camera moves / call sequence, the HIP
 path against the CPU oracle bit for bit (film sums, sums of squares, counts, packed pixels, ray counters).  Test infrastructure.
-usage: [FUZZ_WILD=1] [FUZZ_SPP=1] parity_fuzz.py [cases] [seed]   — prints one line per case, exits 1 on the first difference."""
+usage: [FUZZ_WILD=1] [FUZZ_SPP=1] [FUZZ_SOUP=1] parity_fuzz.py [cases] [seed]   — prints one line per case, exits 1 on the first difference."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +13,26 @@ WILD = bool(os.environ.get("FUZZ_WILD"))
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def soup(base, rng):
+    sc = dict(base)
+    v = base["tri_verts"].reshape(-1, 3); lo, hi = v.min(0), v.max(0); ext = float((hi - lo).max())
+    n = int(rng.choice([1, 2, 3, 7, 30, 150, 600]))
+    centre = rng.uniform(lo, hi, (n, 1, 3))
+    size = ext * 10.0 ** rng.uniform(-4.0, 0.0, (n, 1, 1))
+    t = centre + rng.uniform(-1.0, 1.0, (n, 3, 3)) * size
+    kind = rng.random(n)
+    for i in range(n):
+        if kind[i] < 0.10: t[i, 2] = t[i, 1]                                        # two equal vertices
+        elif kind[i] < 0.15: t[i, 2] = 0.5 * (t[i, 0] + t[i, 1])                    # three vertices on a line
+        elif kind[i] < 0.25 and i: t[i] = t[int(rng.integers(0, i))]                # the same triangle twice (ties go to the lower index)
+        elif kind[i] < 0.40: t[i, :, int(rng.integers(0, 3))] = t[i, 0, int(rng.integers(0, 3))]   # axis-parallel
+        elif kind[i] < 0.45: t[i] = centre[i] + rng.uniform(-3.0, 3.0, (3, 3)) * ext   # reaches far beyond the rest
+        elif kind[i] < 0.50: t[i, 1] = t[i, 0] + (t[i, 1] - t[i, 0]) * 1e-3          # a sliver
+    sc["tri_verts"] = t.astype(np.float32).reshape(n, 9)
+    sc["tri_geom"] = rng.integers(0, len(base["mat_kind"]), size=n).astype(np.uint32)
+    return sc
 
 
 def one_case(pkg, O, scenes, rng, verbose=True):
@@ -30,6 +50,8 @@ def one_case(pkg, O, scenes, rng, verbose=True):
     if rng.random() < 0.3:
         world = int(rng.integers(2, 5)); stripes = dict(stripe_rows=int(rng.choice([1, 2, 4, 8])), stripe_rank=int(rng.integers(0, world)), stripe_world=world)
     sc = scenes(name)
+    if os.environ.get("FUZZ_SOUP") and rng.random() < 0.6:   # FUZZ_SOUP=1: random triangle soups in front of the 4boxes camera — slivers, degenerate and duplicate
+        name = "soup"; sc = soup(scenes("4boxes"), rng)        # triangles, axis-parallel ones, huge ones, sizes over four decades
     if rng.random() < 0.35:                             # the light somewhere else: in, on or around the geometry (the lights' depth maps, the ray's tail behind the light)
         sc = dict(sc); sc["lights"] = sc["lights"].copy()
         v = sc["tri_verts"].reshape(-1, 3); lo, hi = v.min(0), v.max(0)
