@@ -1,6 +1,6 @@
 """Randomised parity: random scene / size / seed / recursion setting / leaf size / semantics / camera moves / call sequence, the HIP
 path against the CPU oracle bit for bit (film sums, sums of squares, counts, packed pixels, ray counters).  Test infrastructure.
-usage: [FUZZ_WILD=1] [FUZZ_SPP=1] [FUZZ_SOUP=1] parity_fuzz.py [cases] [seed]   — prints one line per case, exits 1 on the first difference."""
+usage: [FUZZ_WILD=1] [FUZZ_SPP=1] [FUZZ_SOUP=1] [FUZZ_BUILD=1] parity_fuzz.py [cases] [seed]   — prints one line per case, exits 1 on the first difference."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,6 +60,10 @@ def one_case(pkg, O, scenes, rng, verbose=True):
         elif kind < 0.7: sc["lights"][0, :3] = v[int(rng.integers(0, len(v)))] + rng.normal(0, 1e-3, 3)
         else: sc["lights"][0, :3] = rng.uniform(lo - 2 * (hi - lo), hi + 2 * (hi - lo))
     extra = {}
+    if os.environ.get("FUZZ_BUILD"):                       # FUZZ_BUILD=1: the tree built on the device (LBVH), several members of a device group sharing the one GPU
+        if rng.random() < 0.4: gflags |= pkg.FLAG_DEVICE_LBVH
+        if not stripes and rng.random() < 0.3:
+            extra["device_count"] = int(rng.integers(2, 5)); gflags |= pkg.FLAG_GROUP_SHARES_DEVICE
     big_spp = os.environ.get("FUZZ_SPP") and rng.random() < 0.6      # FUZZ_SPP=1: many samples per pixel on small images (sample groups, passes of odd sample counts)
     if big_spp:
         w, h = min(w, 8 * int(rng.integers(1, 9))), min(h, 8 * int(rng.integers(1, 7)))
@@ -67,7 +71,7 @@ def one_case(pkg, O, scenes, rng, verbose=True):
             extra["samples_per_pass"] = int(rng.choice([1, 2, 3, 5, 8, 12]))
     rt = pkg.create_raytracer_from_arrays(sc, tpl, w, h, seed=seed, recursions=rec, spread=spread, flags=gflags, **stripes, **extra)
     orc = O.Oracle(sc, w, h, tris_per_leaf=tpl, recursions=rec, spread=spread, seed=seed, flags=oflags)
-    desc = "%s %dx%d seed %d rec %d spread %d tpl %d sem %d %s %s" % (name, w, h, seed, rec, spread, tpl, sem, stripes or "", extra or "")
+    desc = "%s %dx%d seed %d rec %d spread %d tpl %d sem %d flags %#x %s %s" % (name, w, h, seed, rec, spread, tpl, sem, gflags, stripes or "", extra or "")
     steps = []
     for _ in range(int(rng.integers(1, 5)) + (1 if WILD else 0)):
         kind = rng.choice(["render", "frame", "move", "clear"], p=[0.4, 0.3, 0.2, 0.1])
