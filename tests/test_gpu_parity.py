@@ -1016,3 +1016,21 @@ def test_randomised_call_sequences_match_the_oracle(pkg, scenes, oracle):
     rng = np.random.default_rng(3)
     for _ in range(30):
         fuzz.one_case(pkg, oracle, scenes, rng, verbose=False)
+
+
+@pytest.mark.parametrize("modes", [("FUZZ_SPP", "FUZZ_SOUP"), ("FUZZ_BUILD", "FUZZ_SOUP"), ("FUZZ_WILD", "FUZZ_SPP", "FUZZ_SOUP", "FUZZ_BUILD")], ids=lambda m: "+".join(x[5:].lower() for x in m))
+def test_randomised_cases_of_the_wider_fuzz_modes(pkg, scenes, oracle, monkeypatch, modes):
+    """The fuzz tool's other dimensions, 25 cases each of a fixed seed: many samples per pixel in passes of odd sample counts, random triangle soups
+    (slivers, degenerate, duplicate, axis-parallel, far-reaching triangles), the device-built tree, device groups sharing the GPU, wild camera
+    moves (the eye inside or behind the geometry).  (profiles/r03_notes.md records 1 800 cases of these modes.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("parity_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "parity_fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    for m in ("FUZZ_WILD", "FUZZ_SPP", "FUZZ_SOUP", "FUZZ_BUILD"):
+        monkeypatch.delenv(m, raising=False)
+    for m in modes:
+        monkeypatch.setenv(m, "1")
+    rng = np.random.default_rng(31 + len(modes))
+    for _ in range(25):
+        fuzz.one_case(pkg, oracle, scenes, rng, verbose=False)

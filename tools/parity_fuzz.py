@@ -8,7 +8,6 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 
 
-WILD = bool(os.environ.get("FUZZ_WILD"))
 
 
 def bits(a):
@@ -36,6 +35,7 @@ def soup(base, rng):
 
 
 def one_case(pkg, O, scenes, rng, verbose=True):
+    WILD = bool(os.environ.get("FUZZ_WILD"))
     name = rng.choice(["ico2", "4boxes", "ico3_tex", "thai2"], p=[0.35, 0.2, 0.2, 0.25])
     w, h = int(rng.integers(4, 161)), int(rng.integers(3, 121))
     if rng.random() < 0.4:                              # sizes whose wave tiles do not straddle row groups: the tile bins of the primary rays engage
