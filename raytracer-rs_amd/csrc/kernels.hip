@@ -309,7 +309,11 @@ __device__ __forceinline__ bool chunk_is_culled(const DCamera& cam, const DPass&
     const uint32_t g0 = chunk * ps.chunk, g1 = g0 + n - 1u;
     uint32_t s0, p0, s1, p1;
     sample_of(ps, g0, s0, p0); sample_of(ps, g1, s1, p1);
-    if (p1 < p0) return false;                                       // pixel-major order: the chunk straddles two sample indices
+    // the chunk must lie inside ONE sample group (npix * G consecutive samples: the pass's pixels once, G samples each).  A chunk that runs into the next
+    // group holds pixels from the end AND the start of the pixel order — with an image of fewer than chunk / G pixels it can even wrap past its own
+    // first pixel, so p1 >= p0 alone does not tell
+    const uint32_t per = ps.npix * ps.sample_group;
+    if (p1 < p0 || g0 / per != g1 / per) return false;
     uint32_t fr0, nr0, xa, ya, fr1, nr1, xb, yb;
     pass_column(ps, cam.width, p0, fr0, nr0, xa, ya);
     pass_column(ps, cam.width, p1, fr1, nr1, xb, yb);

@@ -499,6 +499,23 @@ def test_tiny_and_odd_image_sizes(pkg, oracle, scenes, sem):
         assert np.array_equal(bits(rt.film.pixel_datas()[0]), bits(orc.film()[0])), (w, h)
 
 
+def test_images_of_fewer_pixels_than_a_chunk_with_the_object_at_the_edge(pkg, oracle, scenes, sem):
+    """An image of fewer than 256 pixels: a chunk of primary samples runs past the end of the pixel order and wraps into the next sample index —
+    possibly past its own first pixel, so that "last pixel >= first pixel" does not mean "a run of pixels".  The chunk culling once took such a chunk
+    for the run between its first and last pixel and culled it when the object sat elsewhere in the image (found by the randomised soak with wild
+    camera moves: the object at the right edge of a 24 x 8 image).  Cameras turned so that the object crosses every edge, several sample counts."""
+    for w, h in ((24, 8), (15, 9), (12, 12), (31, 5)):
+        for yaw, pitch in ((0.0, 0.0), (0.35, 0.0), (-0.35, 0.0), (0.5, 0.1), (-0.5, -0.1), (0.0, 0.3), (0.0, -0.3)):
+            rt = make(pkg, scenes, "ico2", w, h, seed=9, flags=sem.gpu)
+            orc = oracle.Oracle(scenes("ico2"), w, h, seed=9, flags=sem.orc)
+            rt.camera.add_y_angle(yaw); orc.camera_add_y_angle(yaw); rt.camera.add_x_angle(pitch); orc.camera_add_x_angle(pitch)
+            for spp in (1, 3, 33):
+                c = rt.render(spp); oc = orc.render(spp, nthreads=4)
+                assert (c.primary, c.bounce, c.shadow, c.primary_hits) == (oc["primary"], oc["bounce"], oc["shadow"], oc["primary_hits"]), (w, h, yaw, pitch, spp)
+            for a, b in zip(rt.film.pixel_datas(), orc.film()):
+                assert np.array_equal(bits(a) if a.dtype != np.uint32 else a, bits(b) if b.dtype != np.uint32 else b), (w, h, yaw, pitch)
+
+
 def test_4k_frame_tiled_over_8_stripes_matches_oracle_on_sampled_rows(pkg, scenes, oracle, sem):
     """BASELINE config 5 in small: thai2 3840x2160 dealt to 8 ranks in stripes of 8 rows; two of the ranks
     are rendered (2 spp) and rows picked from their stripes are bit-identical to the oracle rendering just
