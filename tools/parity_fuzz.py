@@ -62,6 +62,8 @@ def one_case(pkg, O, scenes, rng, verbose=True):
     extra = {}
     if os.environ.get("FUZZ_BUILD"):                       # FUZZ_BUILD=1: the tree built on the device (LBVH), several members of a device group sharing the one GPU
         if rng.random() < 0.4: gflags |= pkg.FLAG_DEVICE_LBVH
+        if sem != 1 and rng.random() < 0.25: gflags |= pkg.FLAG_OCTREE_SEMANTICS     # the direct octree walk (the reference's own traversal, no BVH): same answers as the default path
+        if rng.random() < 0.2: gflags |= pkg.FLAG_COUNT_STEPS                        # the instrumented kernels
         if not stripes and rng.random() < 0.3:
             extra["device_count"] = int(rng.integers(2, 5)); gflags |= pkg.FLAG_GROUP_SHARES_DEVICE
     big_spp = os.environ.get("FUZZ_SPP") and rng.random() < 0.6      # FUZZ_SPP=1: many samples per pixel on small images (sample groups, passes of odd sample counts)
